@@ -1,0 +1,137 @@
+/*
+ * toad_hip.h — C ABI of libtoad_hip.so: the MI355X (gfx950) kernels behind TOAD's
+ * gated-attention MIL hot path (reference: models/model_toad.py, mahmoodlab/TOAD).
+ *
+ * The reference has no native code and no FFI of its own: every op on this path is a
+ * stock PyTorch op called from Python.  Each entry point below therefore cites the
+ * reference *Python call site(s)* it replaces (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - All tensors are dense row-major fp32 in device memory, 16-byte aligned.
+ *    Weights are [out_features, in_features] exactly as nn.Linear stores them.
+ *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no
+ *    allocation, no host synchronisation and keeps no global mutable state (re-entrant;
+ *    callable from PyTorch's autograd thread).  Workspaces are caller-owned; their sizes
+ *    come from the *_ws_bytes() queries.
+ *  - Return value: 0 on success; a negative TOAD_E* code for argument errors; a positive
+ *    hipError_t for launch failures.  toad_last_error() returns a thread-local message.
+ *  - `beta` arguments: out = beta*out + result (beta = 0 overwrites and never reads out).
+ */
+#ifndef TOAD_HIP_H
+#define TOAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TOAD_ABI_VERSION 1
+
+enum { TOAD_OK = 0, TOAD_EINVAL = -1, TOAD_ESHAPE = -2, TOAD_EWORKSPACE = -3, TOAD_EALIGN = -4 };
+enum { TOAD_ACT_NONE = 0, TOAD_ACT_RELU = 1 };
+
+int toad_abi_version(void);
+const char *toad_last_error(void);
+
+/* ---- Linear layers (exact-fp32 MFMA GEMMs) ------------------------------------------ */
+
+/* Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]).   bias may be NULL.
+ * Replaces nn.Linear(+nn.ReLU): models/model_toad.py:59 and :62 (trunk, act=RELU) and the
+ * attention_a / attention_b pre-activations :21,:25 (act=NONE, W = [Wa;Wb] stacked).
+ * Requires K % 4 == 0. */
+int toad_linear_act_fwd_f32(const float *X, const float *W, const float *bias, float *Y,
+                            int64_t M, int64_t K, int64_t N, int act, void *stream);
+
+/* dX[M,K] = (dY[M,N] W[N,K] + addend[M,K]) * (relu_src[M,K] > 0)
+ * `WT` is W transposed, [K,N] row-major (see toad_transpose_f32).  addend and relu_src may be
+ * NULL (no add / no mask); dX may alias addend.
+ * Replaces autograd's mm backward + threshold_backward behind loss.backward()
+ * (utils/core_utils_mtl_concat.py:231) for models/model_toad.py:62 and :21,:25.
+ * Requires N % 4 == 0. */
+int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend,
+                          const float *relu_src, float *dX,
+                          int64_t M, int64_t N, int64_t K, void *stream);
+
+/* dW[N,K] = beta*dW + dY[M,N]^T X[M,K];  db[N] = beta*db + column sums of dY (db may be NULL).
+ * Split over M with a deterministic two-stage reduction through `ws`.
+ * Replaces autograd's weight/bias gradient for every nn.Linear on the path
+ * (models/model_toad.py:59,62,21,25 via utils/core_utils_mtl_concat.py:231).
+ * Requires N % 4 == 0 and K % 4 == 0. */
+size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K);
+int toad_linear_wgrad_f32(const float *dY, const float *X, float *dW, float *db,
+                          int64_t M, int64_t N, int64_t K, float beta,
+                          void *ws, size_t ws_bytes, void *stream);
+
+/* out[cols,rows] = in[rows,cols]^T  (weight transposes for dgrad). */
+int toad_transpose_f32(const float *in, float *out, int64_t rows, int64_t cols, void *stream);
+
+/* ---- Fused gated-attention pooling --------------------------------------------------- */
+
+/* One pass over the bag:
+ *   g[i,:]   = tanh(Pa[i,:]) * sigmoid(Pb[i,:])            models/model_toad.py:37-39
+ *   A_raw[i,t] = g[i,:] . Wc[t,:] + bc[t]                   models/model_toad.py:40
+ *   M[t,:]   = sum_i softmax_i(A_raw[:,t])[i] * H[i,:]      models/model_toad.py:92,97-98
+ * Pa/Pb are the pre-activation rows (row stride ldp floats; Pb = Pa + D when both halves
+ * come from one stacked GEMM).  H may be NULL together with M and stats: then only A_raw
+ * is produced (the attention_only path, models/model_toad.py:93-94).
+ * Outputs: A_raw[N,T] (row-major; the reference's `A` is its transpose view),
+ *          M[T,L], stats[T,2] = (max_i A_raw[i,t], sum_i exp(A_raw[i,t]-max)) for backward.
+ * Supported shapes: T in {1,2}; D in {256,384}; L in {512,1024}; N >= 1. */
+size_t toad_gated_pool_ws_bytes(int64_t N, int L, int D, int T);
+int toad_gated_pool_fwd_f32(const float *Pa, const float *Pb, int64_t ldp, const float *H,
+                            const float *Wc, const float *bc,
+                            float *A_raw, float *M, float *stats,
+                            void *ws, size_t ws_bytes,
+                            int64_t N, int L, int D, int T, void *stream);
+
+/* Backward of the above (autograd mirror, utils/core_utils_mtl_concat.py:231):
+ *   p[i,t]  = exp(A_raw[i,t]-max_t)/sum_t
+ *   dS[i,t] = p[i,t]*(dM[t,:].H[i,:] - dM[t,:].M[t,:]) + dA_ext[i,t]   (dA_ext may be NULL)
+ *   dH[i,:] = sum_t p[i,t]*dM[t,:]
+ *   dPa = (dS Wc) * b*(1-a^2),  dPb = (dS Wc) * a*b*(1-b)   with a=tanh(Pa), b=sigmoid(Pb)
+ *   dWc = beta*dWc + dS^T g,  dbc = beta*dbc + column sums of dS
+ * dPa/dPb have row stride ldd floats. */
+size_t toad_gated_pool_bwd_ws_bytes(int64_t N, int L, int D, int T);
+int toad_gated_pool_bwd_f32(const float *Pa, const float *Pb, int64_t ldp, const float *H,
+                            const float *Wc, const float *A_raw, const float *stats,
+                            const float *M, const float *dM, const float *dA_ext,
+                            float *dPa, float *dPb, int64_t ldd, float *dH,
+                            float *dWc, float *dbc, float beta,
+                            void *ws, size_t ws_bytes,
+                            int64_t N, int L, int D, int T, void *stream);
+
+/* ---- Classifier heads ---------------------------------------------------------------- */
+
+/* models/model_toad.py:99-107:
+ *   Mcat[t,:] = [M[t,:], sex];  logits = Mcat[0] Wcls^T + bcls;  site_logits = Mcat[1] Wsite^T + bsite
+ *   Y_prob/site_prob = softmax;  Y_hat/site_hat = argmax (first maximal index, as torch.topk).
+ * Wcls [C,L+1], Wsite [2,L+1]; sex points at ONE device float. C <= 1024. */
+int toad_heads_fwd_f32(const float *M, const float *sex,
+                       const float *Wcls, const float *bcls, const float *Wsite, const float *bsite,
+                       float *Mcat, float *logits, float *Y_prob, int64_t *Y_hat,
+                       float *site_logits, float *site_prob, int64_t *site_hat,
+                       int L, int C, void *stream);
+
+/* Backward of the heads: dWcls = beta*dWcls + dlogits^T Mcat[0], dbcls, dWsite, dbsite likewise;
+ * dM[t,:] = (d{logits,site}[.] W{cls,site})[:L] + dMcat_ext[t,:L]  (dMcat_ext [2,L+1] may be NULL). */
+int toad_heads_bwd_f32(const float *Mcat, const float *dlogits, const float *dsite,
+                       const float *Wcls, const float *Wsite, const float *dMcat_ext,
+                       float *dWcls, float *dbcls, float *dWsite, float *dbsite, float *dM,
+                       float beta, int L, int C, void *stream);
+
+/* Fused caller-side loss (utils/core_utils_mtl_concat.py:213-215) and its gradient:
+ *   loss = w_cls*CE(logits,label) + w_site*CE(site_logits,site);  dlogits, dsite = d loss/d logits.
+ * label/site point at ONE device int64 each. loss_out[3] = (loss, cls_loss, site_loss). */
+int toad_mtl_ce_fwd_bwd_f32(const float *logits, const float *site_logits,
+                            const int64_t *label, const int64_t *site,
+                            float w_cls, float w_site,
+                            float *loss_out, float *dlogits, float *dsite,
+                            int C, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOAD_HIP_H */

@@ -1,0 +1,109 @@
+"""CPU: the C-ABI library loads and exports every declared symbol; host-side module logic
+(constructor surface, state-dict layout, flat parameter buffer, loud failure without a GPU)."""
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(REPO, "include", "toad_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(toad_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_header_symbol():
+    from toad_amd import _lib
+    lib = _lib.load()                       # dlopen only: no kernel is launched on this box
+    names = header_functions()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/toad_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+    assert lib.toad_abi_version() == _lib.ABI_VERSION
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from toad_amd import _lib
+    lib = _lib.load()
+    rc = lib.toad_linear_act_fwd_f32(None, None, None, None, 4, 4, 4, 0, None)
+    assert rc == -1 and b"null pointer" in lib.toad_last_error()
+    assert lib.toad_gated_pool_ws_bytes(1000, 512, 384, 2) > 0
+    assert lib.toad_gated_pool_ws_bytes(1000, 500, 384, 2) == 0      # unsupported shape
+    assert lib.toad_linear_wgrad_ws_bytes(100000, 512, 1024) >= 512 * 1024 * 4
+
+
+def test_constructor_and_state_dict_match_reference(golden):
+    from toad_amd import TOAD_fc_mtl_concat
+    def plain(fn):      # "(self, gate=True, ...)" without annotations
+        ps = inspect.signature(fn).parameters.values()
+        return "(" + ", ".join(p.name if p.default is p.empty else f"{p.name}={p.default!r}" for p in ps) + ")"
+    assert plain(TOAD_fc_mtl_concat.__init__) == str(golden["api/init_sig"])
+    assert plain(TOAD_fc_mtl_concat.forward) == str(golden["api/forward_sig"])
+    rows = str(golden["api/state_dict"]).split("\n")
+    for c, dr in ((18, False), (2, True)):
+        m = TOAD_fc_mtl_concat(dropout=dr, n_classes=c)
+        mine = [f"{c}|{int(dr)}|{k}|{','.join(map(str, v.shape))}" for k, v in m.state_dict().items()]
+        assert mine == [r for r in rows if r.startswith(f"{c}|{int(dr)}|")]
+    with pytest.raises(NameError):
+        TOAD_fc_mtl_concat(gate=False)      # reference: model_toad.py:68 references an undefined Attn_Net
+
+
+def test_initialisation_is_xavier_normal_zero_bias():
+    from toad_amd import TOAD_fc_mtl_concat
+    torch.manual_seed(1)
+    m = TOAD_fc_mtl_concat(n_classes=18)
+    for k, v in m.state_dict().items():
+        if k.endswith("bias"):
+            assert float(v.abs().max()) == 0.0
+        else:
+            std = (2.0 / (v.shape[0] + v.shape[1])) ** 0.5
+            assert abs(float(v.std()) - std) < 0.15 * std, k
+
+
+def test_flat_parameter_buffer_roundtrip():
+    from toad_amd import TOAD_fc_mtl_concat
+    m = TOAD_fc_mtl_concat(n_classes=18)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    flat = m.flatten_parameters()
+    assert m._is_flat()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k])
+    a = m.attention_net[4].attention_a[0].weight
+    b = m.attention_net[4].attention_b[0].weight
+    assert b.data_ptr() == a.data_ptr() + 4 * a.numel()          # [Wa;Wb] is one zero-copy view
+    assert torch.equal(m._views["wab"], torch.cat([a, b], 0))
+    assert all(p.data_ptr() % 256 == flat.data_ptr() % 256 or k in ("wb", "bb") for k, p in m._slot_params().items())
+    m.load_state_dict(sd)                                          # in-place copy keeps the views
+    assert m._is_flat()
+    m.double().float()                                             # _apply re-homes parameters ...
+    assert not m._is_flat()
+    m.flat_parameters()                                            # ... and the module re-flattens on demand
+    assert m._is_flat()
+    offs, total = m.flat_offsets()
+    assert total == flat.numel() and sum(n for _, n in offs.values()) == 1192490
+
+
+def test_no_cpu_fallback():
+    from toad_amd import TOAD_fc_mtl_concat, Attn_Net_Gated
+    m = TOAD_fc_mtl_concat(n_classes=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(8, 1024), torch.zeros(1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Attn_Net_Gated()(torch.zeros(8, 1024))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            m.relocate()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "toad_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f

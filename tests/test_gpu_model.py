@@ -1,0 +1,144 @@
+"""GPU: the drop-in nn.Module end to end (through the C ABI) against the committed golden
+vectors (the reference's outputs) and against the oracle on random bags; full-size properties."""
+import pytest
+import torch
+
+from oracle import toad_oracle as orc
+from tests.helpers import SLOT2KEY, case_inputs, check_outputs_vs_golden
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["n1", "n2", "n63", "n64", "n65", "n256", "n777", "n777_c2", "n1024_sat", "n300_equal", "n10000", "n100000"]
+
+
+def _model(c, params, cuda):
+    from toad_amd import TOAD_fc_mtl_concat
+    m = TOAD_fc_mtl_concat(dropout=False, n_classes=c)
+    m.load_state_dict(params, strict=True)
+    m.relocate()
+    return m
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_module_matches_reference_golden(cuda, golden, name):
+    """Same call sequence as the reference train loop (utils/core_utils_mtl_concat.py:201-231)."""
+    ci = case_inputs(golden, name)
+    model = _model(ci["c"], ci["params"], cuda)
+    model.train()
+    data, sex = ci["x"].to(cuda), ci["sex"].to(cuda)
+    label, site = ci["label"].to(cuda), ci["site"].to(cuda)
+    res = model(data, sex, return_features=True)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    loss = loss_fn(res["logits"], label) * 0.75 + loss_fn(res["site_logits"], site) * 0.25
+    loss.backward()
+    out = {k: v.detach().cpu() for k, v in res.items()}
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    assert set(grads) == set(orc.PARAM_KEYS)
+    check_outputs_vs_golden(golden, name, out, loss.item(), grads, atol=1e-4)
+    a_only = model(data, sex, attention_only=True)
+    assert a_only.shape == (ci["n"],)
+    assert torch.equal(a_only, res["A"][0].detach())
+
+
+def test_module_random_bag_vs_oracle(cuda):
+    torch.manual_seed(0)
+    from toad_amd import TOAD_fc_mtl_concat
+    model = TOAD_fc_mtl_concat(n_classes=18)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.05)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.relocate()
+    x = torch.randn(5003, 1024); sex = torch.tensor([1.0]); label = torch.tensor([3]); site = torch.tensor([0])
+    res = model(x.to(cuda), sex.to(cuda))
+    loss = orc.loss_fn(res["logits"], label.to(cuda), res["site_logits"], site.to(cuda))
+    loss.backward()
+    o_out, o_loss, o_grads = orc.fwd_bwd(params, x, sex, label, site)
+    for k in ("logits", "Y_prob", "site_logits", "site_prob", "A"):
+        assert (res[k].detach().cpu() - o_out[k]).abs().max().item() <= 1e-4, k
+    assert abs(loss.item() - o_loss.item()) <= 1e-4
+    for k, p in model.named_parameters():
+        ref = o_grads[k]
+        assert (p.grad.cpu() - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-2), k
+
+
+def test_fused_loss_path_equals_autograd_path(cuda):
+    """functional.mil_forward/mil_backward + the fused CE kernel give the same gradients as
+    module + torch CE + autograd, and accumulate (beta=1) into preset destinations."""
+    from toad_amd import TOAD_fc_mtl_concat, functional as F_, ops
+    torch.manual_seed(1)
+    model = TOAD_fc_mtl_concat(n_classes=18); model.relocate()
+    x = torch.randn(3001, 1024, device=cuda); sex = torch.ones(1, device=cuda)
+    label = torch.tensor([5], device=cuda); site = torch.tensor([1], device=cuda)
+    res = model(x, sex)
+    ce = torch.nn.CrossEntropyLoss()
+    (ce(res["logits"], label) * 0.75 + ce(res["site_logits"], site) * 0.25).backward()
+    w = {k: v.detach() for k, v in model._weights().items()}
+    outs, saved = F_.mil_forward(w, x, sex)
+    lossv, dl, ds = ops.mtl_ce_fwd_bwd(outs["logits"], outs["site_logits"], label, site)
+    g, _ = F_.mil_backward(w, saved, dl, ds)
+    sp = model._slot_params()
+    for k in F_.SLOTS:
+        assert torch.equal(g[k], sp[k].grad), k            # same kernels, same order -> bitwise
+    dest = {k: torch.ones_like(sp[k]) for k in F_.SLOTS}
+    g2, _ = F_.mil_backward(w, saved, dl, ds, grads=dest, beta=1.0)
+    for k in F_.SLOTS:
+        assert (dest[k] - (g[k] + 1.0)).abs().max().item() <= 1e-5 * max(g[k].abs().max().item(), 1.0), k
+
+
+def test_full_size_properties_100k(cuda):
+    """BASELINE size (100k x 1024): properties that do not need a CPU oracle run.
+    (1) permutation invariance of the bag; (2) pooled features are a convex combination of rows;
+    (3) run-to-run bitwise determinism of forward and gradients."""
+    from toad_amd import TOAD_fc_mtl_concat
+    torch.manual_seed(2)
+    model = TOAD_fc_mtl_concat(n_classes=18); model.relocate()
+    n = 100000
+    g = torch.Generator(device=cuda).manual_seed(1000)
+    x = torch.randn(n, 1024, device=cuda, generator=g)
+    sex = torch.zeros(1, device=cuda); label = torch.tensor([1], device=cuda); site = torch.tensor([0], device=cuda)
+
+    def run(xx):
+        model.zero_grad(set_to_none=True)
+        r = model(xx, sex, return_features=True)
+        loss = orc.loss_fn(r["logits"], label, r["site_logits"], site)
+        loss.backward()
+        return r, torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+
+    r1, g1 = run(x)
+    r2, g2 = run(x)
+    assert torch.equal(r1["logits"], r2["logits"]) and torch.equal(g1, g2)
+    perm = torch.randperm(n, device=cuda, generator=g)
+    r3, g3 = run(x[perm].contiguous())
+    assert (r3["logits"] - r1["logits"]).abs().max().item() <= 1e-4
+    assert (r3["A"][:, torch.argsort(perm)] - r1["A"]).abs().max().item() <= 1e-5
+    assert (g3 - g1).abs().max().item() <= 1e-4 * max(g1.abs().max().item(), 1e-2)
+    feats = r1["features"][:, :512]
+    assert feats.min().item() >= 0.0                                 # H = relu(...) >= 0, weights >= 0
+    a = torch.softmax(r1["A"].double(), dim=1)
+    assert (a.sum(1) - 1).abs().max().item() < 1e-9
+
+
+def test_attn_net_gated_standalone(cuda):
+    """Attn_Net_Gated with its constructor defaults (L=1024, D=256, n_tasks=1; model_toad.py:19)."""
+    from toad_amd import Attn_Net_Gated
+    torch.manual_seed(4)
+    net = Attn_Net_Gated().to(cuda)
+    x = torch.randn(999, 1024)
+    xg = x.to(cuda).requires_grad_(True)
+    a, xo = net(xg)
+    assert xo is xg and a.shape == (999, 1)
+    wa, ba = net.attention_a[0].weight.detach().cpu(), net.attention_a[0].bias.detach().cpu()
+    wb, bb = net.attention_b[0].weight.detach().cpu(), net.attention_b[0].bias.detach().cpu()
+    wc, bc = net.attention_c.weight.detach().cpu(), net.attention_c.bias.detach().cpu()
+    xr = x.clone().requires_grad_(True)
+    prm = [t.clone().requires_grad_(True) for t in (wa, ba, wb, bb, wc, bc)]
+    ref = orc.gated_scores(torch.addmm(prm[1], xr, prm[0].t()), torch.addmm(prm[3], xr, prm[2].t()), prm[4], prm[5])
+    assert (a.detach().cpu() - ref.detach()).abs().max().item() <= 1e-5
+    a.sin().sum().backward(); ref.sin().sum().backward()
+    mine = [net.attention_a[0].weight, net.attention_a[0].bias, net.attention_b[0].weight, net.attention_b[0].bias,
+            net.attention_c.weight, net.attention_c.bias]
+    for p, r in zip(mine, prm):
+        assert (p.grad.cpu() - r.grad).abs().max().item() <= 1e-4 * max(r.grad.abs().max().item(), 1e-2)
+    assert (xg.grad.cpu() - xr.grad).abs().max().item() <= 1e-4 * max(xr.grad.abs().max().item(), 1e-2)

@@ -1,0 +1,61 @@
+"""CPU: the oracle (oracle/toad_oracle.py) against the committed golden vectors, which are the
+REFERENCE's outputs captured by oracle/pin_against_reference.py in the build container."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import toad_oracle as orc
+from tests.helpers import case_inputs, check_outputs_vs_golden
+
+SMALL = ["n1", "n2", "n63", "n64", "n65", "n256", "n777", "n777_c2", "n1024_sat", "n300_equal", "n10000"]
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_matches_reference_golden(golden, name):
+    ci = case_inputs(golden, name)
+    out, loss, grads = orc.fwd_bwd(ci["params"], ci["x"], ci["sex"], ci["label"], ci["site"])
+    feat, _ = orc.forward(ci["params"], ci["x"], ci["sex"], return_features=True)
+    out = {k: v.detach() for k, v in out.items()}
+    out["features"] = feat["features"]
+    check_outputs_vs_golden(golden, name, out, loss, grads, atol=2e-5)
+
+
+def test_oracle_attention_only(golden):
+    ci = case_inputs(golden, "n777")
+    a = orc.forward(ci["params"], ci["x"], ci["sex"], attention_only=True)
+    assert a.shape == (777,)
+    from tests.helpers import strided_sample
+    assert np.abs(strided_sample(a) - golden["n777/A_only_sample"]).max() <= 2e-5
+
+
+def test_oracle_backward_matches_autograd():
+    """The hand-written backward (the kernels' CPU twin) equals torch autograd on the same graph."""
+    torch.manual_seed(3)
+    params = {k: v.clone().requires_grad_(True) for k, v in orc.xavier_params(18, seed=5).items()}
+    for k in params:
+        if params[k].dim() == 1:
+            params[k].data.normal_(0, 0.05)
+    x = torch.randn(333, 1024)
+    sex = torch.tensor([1.0]); label = torch.tensor([7]); site = torch.tensor([1])
+    out, _ = orc.forward(params, x, sex)
+    loss = orc.loss_fn(out["logits"], label, out["site_logits"], site) + 0.3 * out["A"].sin().sum()
+    loss.backward()
+    with torch.no_grad():
+        p2 = {k: v.detach() for k, v in params.items()}
+        out2, saved = orc.forward(p2, x, sex)
+        dl, ds = orc.loss_grad(out2["logits"], label, out2["site_logits"], site)
+        da = 0.3 * out2["A"].cos().t().contiguous()          # external gradient on A_raw [N,T]
+        g = orc.backward(p2, saved, dl, ds, da_ext=da)
+    for k in orc.PARAM_KEYS:
+        ref = params[k].grad
+        err = (g[k] - ref).abs().max().item()
+        assert err <= 2e-5 * max(ref.abs().max().item(), 1.0), (k, err)
+
+
+def test_closed_form_inputs_are_deterministic():
+    a = orc.closed_form_bag(17).numpy()
+    b = orc.closed_form_bag(17).numpy()
+    assert np.array_equal(a, b) and a.shape == (17, 1024) and np.isfinite(a).all()
+    p = orc.closed_form_params(18)
+    assert set(p) == set(orc.PARAM_KEYS)
+    assert sum(v.numel() for v in p.values()) == 1192490

@@ -1,0 +1,63 @@
+"""ctypes binding of libtoad_hip.so (the C ABI declared in include/toad_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a symbol is absent the import
+fails loudly, and every op refuses non-CUDA tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtoad_hip.so")
+ABI_VERSION = 1
+
+P, I64, I, F, SZ = c_void_p, c_int64, c_int, c_float, c_size_t
+
+# name -> (restype, argtypes); mirrors include/toad_hip.h one to one
+SIGNATURES = {
+    "toad_abi_version": (I, []),
+    "toad_last_error": (c_char_p, []),
+    "toad_linear_act_fwd_f32": (I, [P, P, P, P, I64, I64, I64, I, P]),
+    "toad_linear_dgrad_f32": (I, [P, P, P, P, P, I64, I64, I64, P]),
+    "toad_linear_wgrad_ws_bytes": (SZ, [I64, I64, I64]),
+    "toad_linear_wgrad_f32": (I, [P, P, P, P, I64, I64, I64, F, P, SZ, P]),
+    "toad_transpose_f32": (I, [P, P, I64, I64, P]),
+    "toad_gated_pool_ws_bytes": (SZ, [I64, I, I, I]),
+    "toad_gated_pool_fwd_f32": (I, [P, P, I64, P, P, P, P, P, P, P, SZ, I64, I, I, I, P]),
+    "toad_gated_pool_bwd_ws_bytes": (SZ, [I64, I, I, I]),
+    "toad_gated_pool_bwd_f32": (I, [P, P, I64, P, P, P, P, P, P, P, P, P, I64, P, P, P, F, P, SZ, I64, I, I, I, P]),
+    "toad_heads_fwd_f32": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P]),
+    "toad_heads_bwd_f32": (I, [P, P, P, P, P, P, P, P, P, P, P, F, I, I, P]),
+    "toad_mtl_ce_fwd_bwd_f32": (I, [P, P, P, P, F, F, P, P, P, I, P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """dlopen libtoad_hip.so and bind every declared symbol (raises if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -m toad_amd.build). "
+            "toad_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.toad_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libtoad_hip.so ABI version {got} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().toad_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

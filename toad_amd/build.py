@@ -1,0 +1,55 @@
+"""Build recipe for libtoad_hip.so (hipcc, gfx950 only, in-tree output).
+
+    python -m toad_amd.build            # build if stale
+    python -m toad_amd.build --force
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libtoad_hip.so")
+SOURCES = ["capi.hip", "gemm_f32.hip", "gated_pool.hip", "heads.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(REPO, "include", "toad_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+         "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+
+
+def _stale(obj: str, deps) -> bool:
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + HEADERS):
+            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,561 @@
+// gated_pool.hip — fused gated-attention scores + online-softmax pooling (forward and backward).
+//
+// Replaces, in ONE pass over the bag (models/model_toad.py:37-40 and :92,:97-98):
+//     a = tanh(Pa); b = sigmoid(Pb); A_raw = (a*b) Wc^T + bc; A = softmax_N(A_raw^T); M = A @ H
+// HBM-bound: 4*(2D+L+T) bytes per patch are read exactly once (5,128 B at D=384, L=512, T=2),
+// ~7.4 kFLOP per patch -> 1.4 FLOP/B.  No operand is re-read, nothing is staged twice.
+//
+// Work decomposition (gfx950, wave64):
+//  * 16 lanes own one patch row, so a wave streams 4 rows per step; every 16-lane group reads
+//    contiguous 256-B pieces of its row with 16-B/lane loads (full 128-B lines).
+//    A wave step keeps 6+6 (Pa,Pb) + 8 (H) dwordx4 loads in flight per lane = 20 KB / wave.
+//  * the D-long dot products with Wc are reduced with four DPP steps inside the 16-lane row
+//    (quad_perm, quad_perm, row_half_mirror, row_mirror): no LDS, no ds_bpermute.
+//  * online softmax: each 16-lane group carries (m_t, l_t, acc_t[L/16 columns]) in registers;
+//    the accumulator is rescaled only when a step raises the running max (wave-uniform branch).
+//  * groups -> waves -> block are merged once at the end through LDS, each block writes one
+//    (m, l, acc) partial; a small second kernel merges the partials, normalises and also
+//    emits (max, sum) per task for the backward pass.
+// Tiles of 16 rows are dealt block-cyclically so all blocks sweep HBM together.
+#include "common.h"
+
+#include <math.h>
+
+namespace toad {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr int POOL_THREADS = 256;          // 4 waves
+constexpr int ROWS_PER_BLOCK_STEP = 16;    // 4 waves x 4 rows
+
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+
+// a = tanh(x), b = sigmoid(y) from two v_exp_f32 and two v_rcp_f32.
+//   u = e^{2x} (x clamped to +-20: tanh saturates to 1-4e-18, u stays finite), v = e^{-y}
+//   a = (u-1)/(u+1), b = 1/(1+v).  Absolute error ~1e-7 (fp32 eps) everywhere.
+__device__ __forceinline__ void gate_ab(float x, float y, float &a, float &b) {
+    x = __builtin_fminf(__builtin_fmaxf(x, -20.f), 20.f);
+    const float u = __builtin_amdgcn_exp2f(x * (2.f * kLog2e));
+    const float v = __builtin_amdgcn_exp2f(y * (-kLog2e));
+    a = (u - 1.f) * __builtin_amdgcn_rcpf(u + 1.f);
+    b = __builtin_amdgcn_rcpf(1.f + v);
+}
+// g = a*b with a single reciprocal: (u-1) / ((u+1)(1+v))
+__device__ __forceinline__ float gate_g(float x, float y) {
+    x = __builtin_fminf(__builtin_fmaxf(x, -20.f), 20.f);
+    const float u = __builtin_amdgcn_exp2f(x * (2.f * kLog2e));
+    const float v = __builtin_amdgcn_exp2f(y * (-kLog2e));
+    return (u - 1.f) * __builtin_amdgcn_rcpf((u + 1.f) * (1.f + v));
+}
+
+// Partial record written by each block: [T][L] acc then [T][2] (m,l)
+__host__ __device__ inline int64_t pool_partial_floats(int L, int T) { return (int64_t)T * L + 2 * T; }
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+template <int T, int DQ /* = D/64 float4 per lane */, int LQ /* = L/64 float4 per lane */, bool POOL>
+__global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
+    const float *__restrict__ Pa, const float *__restrict__ Pb, int64_t ldp, const float *__restrict__ H,
+    const float *__restrict__ Wc, const float *__restrict__ bc, float *__restrict__ A_raw,
+    float *__restrict__ partials, int N) {
+    constexpr int D = DQ * 64, L = LQ * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane >> 4, c = lane & 15;       // 16-lane group = one row; c = float4 slot
+
+    // Wc columns owned by this lane: float4 index c + 16 j
+    f32x4 wc[T][DQ];
+    float bcv[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        bcv[t] = bc[t];
+#pragma unroll
+        for (int j = 0; j < DQ; ++j) wc[t][j] = ld4(Wc + t * D + (c + 16 * j) * 4);
+    }
+
+    float m[T], l[T];
+    f32x4 acc[T][POOL ? LQ : 1];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        m[t] = -INFINITY;
+        l[t] = 0.f;
+#pragma unroll
+        for (int j = 0; j < (POOL ? LQ : 1); ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int ntiles = (N + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row = tile * ROWS_PER_BLOCK_STEP + wave * 4 + grp;
+        const bool valid = row < N;
+        const int64_t rr = valid ? row : 0;
+        const float *pa = Pa + rr * ldp + c * 4;
+        const float *pb = Pb + rr * ldp + c * 4;
+        f32x4 xa[DQ], xb[DQ];
+#pragma unroll
+        for (int j = 0; j < DQ; ++j) {
+            xa[j] = ld4(pa + 64 * j);
+            xb[j] = ld4(pb + 64 * j);
+        }
+        f32x4 hv[POOL ? LQ : 1];
+        if (POOL) {
+            const float *hp = H + rr * L + c * 4;
+#pragma unroll
+            for (int j = 0; j < LQ; ++j) hv[j] = ld4(hp + 64 * j);
+        }
+
+        float s[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) s[t] = 0.f;
+#pragma unroll
+        for (int j = 0; j < DQ; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = gate_g(xa[j][e], xb[j][e]);
+#pragma unroll
+                for (int t = 0; t < T; ++t) s[t] = fmaf(g, wc[t][j][e], s[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) s[t] = row16_allreduce_sum(s[t]) + bcv[t];
+
+        if (valid && c == 0) {
+            if (T == 2) {
+                *reinterpret_cast<f32x2 *>(A_raw + (int64_t)row * 2) = f32x2{s[0], s[T - 1]};
+            } else {
+#pragma unroll
+                for (int t = 0; t < T; ++t) A_raw[(int64_t)row * T + t] = s[t];
+            }
+        }
+
+        if (POOL) {
+            float mn[T];
+            bool grow = false;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                mn[t] = valid ? __builtin_fmaxf(m[t], s[t]) : m[t];
+                grow |= mn[t] > m[t];
+            }
+            if (__any(grow)) {   // wave-uniform: rescale the running sums to the new max
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float f = (mn[t] > m[t]) ? fast_exp(m[t] - mn[t]) : 1.f;   // exp(-inf)=0 on first row
+                    l[t] *= f;
+#pragma unroll
+                    for (int j = 0; j < LQ; ++j) acc[t][j] *= f;
+                    m[t] = mn[t];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float w = valid ? fast_exp(s[t] - m[t]) : 0.f;
+                l[t] += w;
+#pragma unroll
+                for (int j = 0; j < LQ; ++j) acc[t][j] += w * hv[j];
+            }
+        }
+    }
+
+    if (!POOL) return;
+
+    // ---- merge the 16 (group, wave) partials of this block -------------------------------
+    __shared__ float sm_m[16][T];
+    __shared__ __attribute__((aligned(16))) float sm_acc[4][T][L];
+    __shared__ float sm_l[4][T];
+    __shared__ float sm_mb[T];
+    if (c == 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) sm_m[wave * 4 + grp][t] = m[t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        float mb = sm_m[0][t];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) mb = __builtin_fmaxf(mb, sm_m[k][t]);
+        const float f = (m[t] == -INFINITY) ? 0.f : fast_exp(m[t] - mb);
+        float lt = l[t] * f;
+        // sum the 4 groups of the wave: lanes c, c+16, c+32, c+48 hold the same columns
+        lt += __shfl_xor(lt, 16);
+        lt += __shfl_xor(lt, 32);
+#pragma unroll
+        for (int j = 0; j < LQ; ++j) {
+            f32x4 v = acc[t][j] * f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[e];
+                x += __shfl_xor(x, 16);
+                x += __shfl_xor(x, 32);
+                v[e] = x;
+            }
+            if (grp == 0) st4(&sm_acc[wave][t][(c + 16 * j) * 4], v);
+        }
+        if (lane == 0) sm_l[wave][t] = lt;
+        if (tid == 0) sm_mb[t] = mb;   // block max (same value in every thread)
+    }
+    __syncthreads();
+    float *out = partials + (int64_t)blockIdx.x * pool_partial_floats(L, T);
+    for (int e = tid; e < T * L / 4; e += POOL_THREADS) {
+        const int t = e / (L / 4), q = e % (L / 4);
+        f32x4 v = ld4(&sm_acc[0][t][q * 4]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += ld4(&sm_acc[w][t][q * 4]);
+        st4(out + t * L + q * 4, v);
+    }
+    if (tid < T) {
+        out[T * L + 2 * tid] = sm_mb[tid];
+        out[T * L + 2 * tid + 1] = sm_l[0][tid] + sm_l[1][tid] + sm_l[2][tid] + sm_l[3][tid];
+    }
+}
+
+// Merge G block partials: M[t,:] = sum_b exp(m_b - m) acc_b / l ; stats[t] = (m, l).
+// grid = (T*L/16) blocks; block = 256 threads = 4 float4 columns x 64 partial slices.
+__global__ __launch_bounds__(256) void gated_pool_combine_kernel(const float *__restrict__ partials, int G, int L,
+                                                                  int T, float *__restrict__ M,
+                                                                  float *__restrict__ stats) {
+    __shared__ float red[256];
+    __shared__ __attribute__((aligned(16))) float sacc[64][16];
+    const int tid = threadIdx.x;
+    const int64_t rec = pool_partial_floats(L, T);
+    const int blocks_per_t = L / 16;
+    const int t = blockIdx.x / blocks_per_t, col0 = (blockIdx.x % blocks_per_t) * 16;
+
+    // global max and sum for task t
+    float mx = -INFINITY;
+    for (int b = tid; b < G; b += 256) mx = __builtin_fmaxf(mx, partials[b * rec + T * L + 2 * t]);
+    red[tid] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = __builtin_fmaxf(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    mx = red[0];
+    __syncthreads();
+    float ls = 0.f;
+    for (int b = tid; b < G; b += 256) {
+        const float mb = partials[b * rec + T * L + 2 * t];
+        if (mb != -INFINITY) ls += partials[b * rec + T * L + 2 * t + 1] * fast_exp(mb - mx);
+    }
+    red[tid] = ls;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    ls = red[0];
+
+    const int q = tid & 3, slice = tid >> 2;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int b = slice; b < G; b += 64) {
+        const float mb = partials[b * rec + T * L + 2 * t];
+        if (mb != -INFINITY) a += fast_exp(mb - mx) * ld4(partials + b * rec + t * L + col0 + q * 4);
+    }
+    st4(&sacc[slice][q * 4], a);
+    __syncthreads();
+    if (tid < 16) {
+        float v = 0.f;
+#pragma unroll 8
+        for (int s = 0; s < 64; ++s) v += sacc[s][tid];
+        M[t * L + col0 + tid] = v / ls;
+    }
+    if (blockIdx.x % blocks_per_t == 0 && tid == 0) {
+        stats[2 * t] = mx;
+        stats[2 * t + 1] = ls;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------
+// Per-block partial: [T][D] dWc then [T] dbc
+__host__ __device__ inline int64_t bwd_partial_floats(int D, int T) { return (int64_t)T * D + T; }
+
+template <int T, int DQ, int LQ>
+__global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
+    const float *__restrict__ Pa, const float *__restrict__ Pb, int64_t ldp, const float *__restrict__ H,
+    const float *__restrict__ Wc, const float *__restrict__ A_raw, const float *__restrict__ stats,
+    const float *__restrict__ Mp, const float *__restrict__ dM, const float *__restrict__ dA_ext,
+    float *__restrict__ dPa, float *__restrict__ dPb, int64_t ldd, float *__restrict__ dH,
+    float *__restrict__ partials, int N) {
+    constexpr int D = DQ * 64, L = LQ * 64;
+    __shared__ __attribute__((aligned(16))) float s_dm[T][L];
+    __shared__ __attribute__((aligned(16))) float s_wc[T][D];
+    __shared__ __attribute__((aligned(16))) float s_red[4][T][D];
+    __shared__ float s_c[T];
+    __shared__ float s_db[4][T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane >> 4, c = lane & 15;
+
+    for (int e = tid; e < T * L; e += POOL_THREADS) s_dm[e / L][e % L] = dM[e];
+    for (int e = tid; e < T * D; e += POOL_THREADS) s_wc[e / D][e % D] = Wc[e];
+    // c_t = dM[t] . M[t]  (one wave per task, fixed order)
+    if (wave < T) {
+        float p = 0.f;
+        for (int e = lane; e < L; e += 64) p = fmaf(dM[wave * L + e], Mp[wave * L + e], p);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+        if (lane == 0) s_c[wave] = p;
+    }
+    __syncthreads();
+
+    float mt[T], il[T], ct[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        mt[t] = stats[2 * t];
+        il[t] = 1.f / stats[2 * t + 1];
+        ct[t] = s_c[t];
+    }
+    f32x4 dwc[T][DQ];
+    float dbc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        dbc[t] = 0.f;
+#pragma unroll
+        for (int j = 0; j < DQ; ++j) dwc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int ntiles = (N + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row = tile * ROWS_PER_BLOCK_STEP + wave * 4 + grp;
+        const bool valid = row < N;
+        const int64_t rr = valid ? row : 0;
+        // issue every load of the step up front
+        const float *hp = H + rr * L + c * 4;
+        f32x4 hv[LQ];
+#pragma unroll
+        for (int j = 0; j < LQ; ++j) hv[j] = ld4(hp + 64 * j);
+        const float *pa = Pa + rr * ldp + c * 4;
+        const float *pb = Pb + rr * ldp + c * 4;
+        f32x4 xa[DQ], xb[DQ];
+#pragma unroll
+        for (int j = 0; j < DQ; ++j) {
+            xa[j] = ld4(pa + 64 * j);
+            xb[j] = ld4(pb + 64 * j);
+        }
+        float p[T], ds[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float s = A_raw[rr * T + t];
+            p[t] = valid ? fast_exp(s - mt[t]) * il[t] : 0.f;
+            ds[t] = (dA_ext && valid) ? dA_ext[rr * T + t] : 0.f;
+        }
+
+        // --- H side: dot_t = dM[t].H[row], dH[row] = sum_t p_t dM[t]
+        float dot[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) dot[t] = 0.f;
+        float *dhp = dH + rr * L + c * 4;
+#pragma unroll
+        for (int j = 0; j < LQ; ++j) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f32x4 d = ld4(&s_dm[t][(c + 16 * j) * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dot[t] = fmaf(d[e], hv[j][e], dot[t]);
+                o += p[t] * d;
+            }
+            if (valid) st4(dhp + 64 * j, o);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            dot[t] = row16_allreduce_sum(dot[t]);
+            ds[t] += p[t] * (dot[t] - ct[t]);
+            if (c == 0) dbc[t] += ds[t];
+        }
+
+        // --- P side
+        float *dpa = dPa + rr * ldd + c * 4;
+        float *dpb = dPb + rr * ldd + c * 4;
+#pragma unroll
+        for (int j = 0; j < DQ; ++j) {
+            f32x4 oa, ob;
+            f32x4 w[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) w[t] = ld4(&s_wc[t][(c + 16 * j) * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a, b;
+                gate_ab(xa[j][e], xb[j][e], a, b);
+                const float g = a * b;
+                float dg = 0.f;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    dg = fmaf(ds[t], w[t][e], dg);
+                    dwc[t][j][e] = fmaf(ds[t], g, dwc[t][j][e]);
+                }
+                oa[e] = dg * b * (1.f - a * a);
+                ob[e] = dg * g * (1.f - b);
+            }
+            if (valid) {
+                st4(dpa + 64 * j, oa);
+                st4(dpb + 64 * j, ob);
+            }
+        }
+    }
+
+    // ---- block reduction of dWc / dbc partials (fixed order) ----------------------------
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        float b = dbc[t];   // non-zero only on c == 0 lanes
+        b += __shfl_xor(b, 16);
+        b += __shfl_xor(b, 32);
+        if (lane == 0) s_db[wave][t] = b;
+#pragma unroll
+        for (int j = 0; j < DQ; ++j) {
+            f32x4 v = dwc[t][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[e];
+                x += __shfl_xor(x, 16);
+                x += __shfl_xor(x, 32);
+                v[e] = x;
+            }
+            if (grp == 0) st4(&s_red[wave][t][(c + 16 * j) * 4], v);
+        }
+    }
+    __syncthreads();
+    float *out = partials + (int64_t)blockIdx.x * bwd_partial_floats(D, T);
+    for (int e = tid; e < T * D / 4; e += POOL_THREADS) {
+        const int t = e / (D / 4), q = e % (D / 4);
+        f32x4 v = ld4(&s_red[0][t][q * 4]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += ld4(&s_red[w][t][q * 4]);
+        st4(out + t * D + q * 4, v);
+    }
+    if (tid < T) out[T * D + tid] = s_db[0][tid] + s_db[1][tid] + s_db[2][tid] + s_db[3][tid];
+}
+
+// out[e] = beta*out[e] + sum_b partials[b][e]; e < n (two destinations: dWc [T*D] then dbc [T])
+__global__ __launch_bounds__(256) void bwd_partial_reduce_kernel(const float *__restrict__ partials, int G, int64_t rec,
+                                                                  int n_w, int n_b, float *dWc, float *dbc,
+                                                                  float beta) {
+    __shared__ float red[4][64];
+    const int tid = threadIdx.x, colq = tid & 63, slice = tid >> 6;
+    const int e = blockIdx.x * 64 + colq;
+    float v = 0.f;
+    if (e < n_w + n_b)
+        for (int b = slice; b < G; b += 4) v += partials[b * rec + e];
+    red[slice][colq] = v;
+    __syncthreads();
+    if (slice == 0 && e < n_w + n_b) {
+        v = red[0][colq] + red[1][colq] + red[2][colq] + red[3][colq];
+        float *dst = e < n_w ? dWc + e : dbc + (e - n_w);
+        *dst = (beta != 0.f ? beta * *dst : 0.f) + v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int pool_grid(int64_t N) {
+    const int64_t ntiles = (N + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP;
+    const int64_t cap = 256 * 3;   // 3 resident blocks per CU (VGPR-limited), block-cyclic tiles
+    return (int)(ntiles < cap ? ntiles : cap);
+}
+
+static bool shape_ok(int L, int D, int T) {
+    return (T == 1 || T == 2) && (D == 256 || D == 384) && (L == 512 || L == 1024);
+}
+
+template <bool POOL>
+static void launch_fwd(int L, int D, int T, int grid, hipStream_t st, const float *Pa, const float *Pb, int64_t ldp,
+                       const float *H, const float *Wc, const float *bc, float *A_raw, float *partials, int N) {
+#define TOAD_FWD_CASE(TT, DD, LL)                                                                             \
+    if (T == TT && D == DD && L == LL) {                                                                      \
+        hipLaunchKernelGGL((gated_pool_fwd_kernel<TT, DD / 64, LL / 64, POOL>), dim3(grid), dim3(POOL_THREADS), 0, st, \
+                           Pa, Pb, ldp, H, Wc, bc, A_raw, partials, N);                                       \
+        return;                                                                                               \
+    }
+    TOAD_FWD_CASE(2, 384, 512)
+    TOAD_FWD_CASE(2, 256, 512)
+    TOAD_FWD_CASE(1, 384, 512)
+    TOAD_FWD_CASE(1, 256, 512)
+    TOAD_FWD_CASE(2, 384, 1024)
+    TOAD_FWD_CASE(2, 256, 1024)
+    TOAD_FWD_CASE(1, 384, 1024)
+    TOAD_FWD_CASE(1, 256, 1024)
+#undef TOAD_FWD_CASE
+}
+
+static void launch_bwd(int L, int D, int T, int grid, hipStream_t st, const float *Pa, const float *Pb, int64_t ldp,
+                       const float *H, const float *Wc, const float *A_raw, const float *stats, const float *M,
+                       const float *dM, const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH,
+                       float *partials, int N) {
+#define TOAD_BWD_CASE(TT, DD, LL)                                                                             \
+    if (T == TT && D == DD && L == LL) {                                                                      \
+        hipLaunchKernelGGL((gated_pool_bwd_kernel<TT, DD / 64, LL / 64>), dim3(grid), dim3(POOL_THREADS), 0, st, Pa, \
+                           Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, partials, N);      \
+        return;                                                                                               \
+    }
+    TOAD_BWD_CASE(2, 384, 512)
+    TOAD_BWD_CASE(2, 256, 512)
+    TOAD_BWD_CASE(1, 384, 512)
+    TOAD_BWD_CASE(1, 256, 512)
+    TOAD_BWD_CASE(2, 384, 1024)
+    TOAD_BWD_CASE(2, 256, 1024)
+    TOAD_BWD_CASE(1, 384, 1024)
+    TOAD_BWD_CASE(1, 256, 1024)
+#undef TOAD_BWD_CASE
+}
+
+}  // namespace toad
+
+using namespace toad;
+
+extern "C" size_t toad_gated_pool_ws_bytes(int64_t N, int L, int D, int T) {
+    if (N <= 0 || !shape_ok(L, D, T)) return 0;
+    return (size_t)pool_grid(N) * (size_t)pool_partial_floats(L, T) * sizeof(float);
+}
+
+extern "C" int toad_gated_pool_fwd_f32(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc,
+                                        const float *bc, float *A_raw, float *M, float *stats, void *ws,
+                                        size_t ws_bytes, int64_t N, int L, int D, int T, void *stream) {
+    const char *what = "toad_gated_pool_fwd_f32";
+    if (!Pa || !Pb || !Wc || !bc || !A_raw) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (N <= 0 || N > INT32_MAX - 64) { set_error("%s: bad N=%lld", what, (long long)N); return TOAD_EINVAL; }
+    if (!shape_ok(L, D, T)) { set_error("%s: unsupported shape L=%d D=%d T=%d (T in {1,2}, D in {256,384}, L in {512,1024})", what, L, D, T); return TOAD_ESHAPE; }
+    if (ldp < D || ldp % 4 != 0) { set_error("%s: bad ldp=%lld", what, (long long)ldp); return TOAD_ESHAPE; }
+    if (!aligned16(Pa) || !aligned16(Pb) || !aligned16(Wc) || (H && !aligned16(H)) || (T == 2 && ((uintptr_t)A_raw & 7))) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = pool_grid(N);
+    if (!H) {
+        if (M || stats) { set_error("%s: M/stats requested without H", what); return TOAD_EINVAL; }
+        launch_fwd<false>(L, D, T, grid, st, Pa, Pb, ldp, nullptr, Wc, bc, A_raw, nullptr, (int)N);
+        return check_launch(what);
+    }
+    if (!M || !stats || !ws) { set_error("%s: null output/workspace", what); return TOAD_EINVAL; }
+    if (!aligned16(ws)) { set_error("%s: workspace must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (ws_bytes < toad_gated_pool_ws_bytes(N, L, D, T)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
+    launch_fwd<true>(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, bc, A_raw, (float *)ws, (int)N);
+    int rc = check_launch(what);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gated_pool_combine_kernel, dim3(T * L / 16), dim3(256), 0, st, (const float *)ws, grid, L, T, M, stats);
+    return check_launch(what);
+}
+
+extern "C" size_t toad_gated_pool_bwd_ws_bytes(int64_t N, int L, int D, int T) {
+    if (N <= 0 || !shape_ok(L, D, T)) return 0;
+    return (size_t)pool_grid(N) * (size_t)bwd_partial_floats(D, T) * sizeof(float);
+}
+
+extern "C" int toad_gated_pool_bwd_f32(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc,
+                                        const float *A_raw, const float *stats, const float *M, const float *dM,
+                                        const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH,
+                                        float *dWc, float *dbc, float beta, void *ws, size_t ws_bytes, int64_t N,
+                                        int L, int D, int T, void *stream) {
+    const char *what = "toad_gated_pool_bwd_f32";
+    if (!Pa || !Pb || !H || !Wc || !A_raw || !stats || !M || !dM || !dPa || !dPb || !dH || !dWc || !dbc || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (N <= 0 || N > INT32_MAX - 64) { set_error("%s: bad N", what); return TOAD_EINVAL; }
+    if (!shape_ok(L, D, T)) { set_error("%s: unsupported shape L=%d D=%d T=%d", what, L, D, T); return TOAD_ESHAPE; }
+    if (ldp < D || ldp % 4 != 0 || ldd < D || ldd % 4 != 0) { set_error("%s: bad row stride", what); return TOAD_ESHAPE; }
+    if (!aligned16(Pa) || !aligned16(Pb) || !aligned16(H) || !aligned16(dPa) || !aligned16(dPb) || !aligned16(dH) || !aligned16(ws)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (ws_bytes < toad_gated_pool_bwd_ws_bytes(N, L, D, T)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = pool_grid(N);
+    launch_bwd(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, (float *)ws, (int)N);
+    int rc = check_launch(what);
+    if (rc) return rc;
+    const int n = T * D + T;
+    hipLaunchKernelGGL(bwd_partial_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float *)ws, grid,
+                       bwd_partial_floats(D, T), T * D, T, dWc, dbc, beta);
+    return check_launch(what);
+}

@@ -1,0 +1,387 @@
+// gemm_f32.hip — exact-fp32 MFMA GEMMs for the Linear layers of TOAD's MIL path (gfx950).
+//
+// Why fp32 MFMA: parity with the reference's PyTorch-CPU path is 1e-4 on fp32 outputs and
+// plain bf16 operands miss it (1e-3..6e-3). gfx950 has no TF32/xf32, but
+// v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain at the fp32 vector peak (157.3 TF).
+//
+// Two kernels cover every product on the path:
+//   gemm_nt : C[M,N] = epi(A[M,K] . B[N,K]^T)        both operands reduction-contiguous
+//             forward  Y = act(X W^T + b)             models/model_toad.py:59,62,21,25
+//             dgrad    dX = (dY (W^T)^T + add)*mask   with WT = W^T materialised once (2 MB)
+//   gemm_tn : C[I,J] = sum_m A[m,I] . B[m,J]         both operands reduction-strided
+//             wgrad    dW = dY^T X, split over m, deterministic slab reduction
+//
+// Tiling (both): 128x128 block tile, 32-deep reduction step, 256 threads = 4 waves in 2x2,
+// each wave a 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 acc VGPRs). LDS is double
+// buffered through registers (global -> VGPR -> LDS) so the next tile's HBM latency hides
+// under 64 MFMAs (4096 issue cycles) per wave; one barrier per step.
+// The k-order inside a step is permuted (lane-half hi supplies k = 8q+4hi+s) so the NT
+// operand fragments are single ds_read_b128's; LDS rows are padded to 36 floats which makes
+// those reads conflict-free for the gfx950 ds_read_b128 lane groups.
+#include "common.h"
+
+namespace toad {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int NT_LD = 36;                                  // padded LDS row (floats), conflict-free b128
+constexpr int NT_TILE = BM * NT_LD;                        // floats per operand tile
+constexpr int NT_SMEM = 2 * 2 * NT_TILE * (int)sizeof(float);   // 73,728 B -> 2 blocks / CU
+constexpr int TN_LD = 128;
+constexpr int TN_TILE = BK * TN_LD;
+constexpr int TN_SMEM = 2 * 2 * TN_TILE * (int)sizeof(float);   // 65,536 B
+
+// XCD-aware block -> tile map: all column tiles of one row tile run on the same XCD (same L2),
+// back to back, so the A panel is fetched from HBM once and re-read from L2.
+__device__ __forceinline__ bool map_tile(int tiles_m, int tiles_n, int &tm, int &tn) {
+    const int b = blockIdx.x;
+    const int xcd = b % kNumXCD, q = b / kNumXCD;
+    tm = (q / tiles_n) * kNumXCD + xcd;
+    tn = q % tiles_n;
+    return tm < tiles_m;
+}
+
+// ------------------------------------------------------------------------------------------
+// NT: C[M,N] = epi(A[M,K] B[N,K]^T);   epi: +bias[col], +addend[row,col], relu, mask(mask_src>0)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(
+    const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
+    float *C, int64_t ldc, int M, int N, int K,
+    const float *__restrict__ bias, int relu, const float *addend, const float *__restrict__ mask_src,
+    int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int tm, tn;
+    if (!map_tile(tiles_m, tiles_n, tm, tn)) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x;
+    const int c4 = tid & 7, r0 = tid >> 3;     // staging: float4 column, first row
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, hi = lane >> 5;
+
+    const float *ap[4], *bp[4];
+    bool aok[4], bok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ra = m0 + r0 + 32 * j, rb = n0 + r0 + 32 * j;
+        aok[j] = ra < M;
+        bok[j] = rb < N;
+        ap[j] = A + (int64_t)(aok[j] ? ra : 0) * lda + c4 * 4;
+        bp[j] = B + (int64_t)(bok[j] ? rb : 0) * ldb + c4 * 4;
+    }
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+        const bool kok = (k0 + c4 * 4) < K;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ra[j] = (aok[j] && kok) ? ld4(ap[j] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[j] = (bok[j] && kok) ? ld4(bp[j] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&](int buf) {
+        float *As = smem + buf * 2 * NT_TILE, *Bs = As + NT_TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            st4(As + (r0 + 32 * j) * NT_LD + c4 * 4, ra[j]);
+            st4(Bs + (r0 + 32 * j) * NT_LD + c4 * 4, rb[j]);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = (K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const bool more = (t + 1) < nk;
+        if (more) gload((t + 1) * BK);
+        const float *As = smem + (t & 1) * 2 * NT_TILE, *Bs = As + NT_TILE;
+        const float *arow = As + (wm * 64 + li) * NT_LD + hi * 4;
+        const float *brow = Bs + (wn * 64 + li) * NT_LD + hi * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 fa[2], fb[2];
+            fa[0] = ld4(arow + q * 8);
+            fa[1] = ld4(arow + 32 * NT_LD + q * 8);
+            fb[0] = ld4(brow + q * 8);
+            fb[1] = ld4(brow + 32 * NT_LD + q * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
+        }
+        if (more) lstore((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: acc reg r of lane (li,hi) is row (r&3)+8*(r>>2)+4*hi, column li of the 32x32 tile
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = n0 + wn * 64 + b * 32 + li;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row >= M) continue;
+                const int64_t off = (int64_t)row * ldc + col;
+                float v = acc[a][b][r] + bv;
+                if (addend) v += addend[off];
+                if (relu) v = v > 0.f ? v : 0.f;
+                if (mask_src) v = mask_src[off] > 0.f ? v : 0.f;
+                C[off] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN (wgrad): slab[s][I,J] = sum_{m in split s} A[m,I] B[m,J];  colsum slab[s][I] = sum_m A[m,I]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(
+    const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
+    float *slab, float *colsum_slab, int Mred, int I, int J, int rows_per_split,
+    int tiles_i, int tiles_j, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tiles = tiles_i * tiles_j;
+    const int bid = blockIdx.x;
+    const int xcd = bid % kNumXCD, q = bid / kNumXCD;
+    const int split = (q / tiles) * kNumXCD + xcd;   // all tiles of one split share an XCD's L2
+    if (split >= nsplit) return;
+    const int tile = q % tiles;
+    const int ti = tile / tiles_j, tj = tile % tiles_j;
+    const int i0 = ti * BM, j0 = tj * BN;
+    const int mbeg = split * rows_per_split;
+    const int mend = min(Mred, mbeg + rows_per_split);
+
+    const int tid = threadIdx.x;
+    const int c4 = tid & 31, r0 = tid >> 5;     // staging: float4 column (of 32), first row (of 8)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, hi = lane >> 5;
+    const bool aok = (i0 + c4 * 4) < I, bok = (j0 + c4 * 4) < J;
+    const float *ap = A + i0 + c4 * 4, *bp = B + j0 + c4 * 4;
+
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int mt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mt + r0 + 8 * j;
+            const bool ok = m < mend;
+            ra[j] = (ok && aok) ? ld4(ap + (int64_t)m * lda) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[j] = (ok && bok) ? ld4(bp + (int64_t)m * ldb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&](int buf) {
+        float *As = smem + buf * 2 * TN_TILE, *Bs = As + TN_TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            st4(As + (r0 + 8 * j) * TN_LD + c4 * 4, ra[j]);
+            st4(Bs + (r0 + 8 * j) * TN_LD + c4 * 4, rb[j]);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum = 0.f;
+    const bool do_colsum = (colsum_slab != nullptr) && (tj == 0) && (tid < BM);
+
+    const int nk = (mend - mbeg + BK - 1) / BK;
+    if (nk > 0) {
+        gload(mbeg);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const bool more = (t + 1) < nk;
+        if (more) gload(mbeg + (t + 1) * BK);
+        const float *As = smem + (t & 1) * 2 * TN_TILE, *Bs = As + TN_TILE;
+        // operand fragments: lane (li,hi) reads floats (2li, 2li+1) of row 2s+hi -> sub-tiles 0/1
+        const float *acol = As + hi * TN_LD + wm * 64 + 2 * li;
+        const float *bcol = Bs + hi * TN_LD + wn * 64 + 2 * li;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const f32x2 fa = *reinterpret_cast<const f32x2 *>(acol + 2 * s * TN_LD);
+            const f32x2 fb = *reinterpret_cast<const f32x2 *>(bcol + 2 * s * TN_LD);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        if (do_colsum) {
+#pragma unroll
+            for (int r = 0; r < BK; ++r) bsum += As[r * TN_LD + tid];
+        }
+        if (more) lstore((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: sub-tile (a,b) element (ri, li) is output (i0+wm*64+2*ri+a, j0+wn*64+2*li+b)
+    float *out = slab + (int64_t)split * I * J;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ri = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int row = i0 + wm * 64 + 2 * ri + a;
+            const int col = j0 + wn * 64 + 2 * li;
+            if (row < I && col < J) {   // J % 2 == 0 (J % 4 == 0 is required)
+                f32x2 v = {acc[a][0][r], acc[a][1][r]};
+                *reinterpret_cast<f32x2 *>(out + (int64_t)row * J + col) = v;
+            }
+        }
+    }
+    if (do_colsum && (i0 + tid) < I) colsum_slab[(int64_t)split * I + i0 + tid] = bsum;
+}
+
+// out[e] = beta*out[e] + sum_s slab[s][e]   (fixed order -> run-to-run deterministic)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab, float *out,
+                                                           int64_t n, int nsplit, float beta) {
+    const int64_t n4 = n >> 2;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 s = ld4(slab + e * 4);
+        for (int k = 1; k < nsplit; ++k) s += ld4(slab + (int64_t)k * n + e * 4);
+        if (beta != 0.f) s += beta * ld4(out + e * 4);
+        st4(out + e * 4, s);
+    }
+}
+
+// 32x32 LDS transpose
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                         int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (by + j < rows && bx + tx < cols) tile[j][tx] = in[(int64_t)(by + j) * cols + bx + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (bx + j < cols && by + tx < rows) out[(int64_t)(bx + j) * rows + by + tx] = tile[tx][j];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, const float *bias, int relu, const float *addend,
+                     const float *mask_src, hipStream_t st, const char *what) {
+    if (M <= 0 || N <= 0 || K <= 0) { set_error("%s: non-positive dimension", what); return TOAD_EINVAL; }
+    if (M > INT32_MAX - BM || N > INT32_MAX - BN || K > INT32_MAX - BK) { set_error("%s: dimension too large", what); return TOAD_ESHAPE; }
+    if (K % 4 != 0 || lda % 4 != 0 || ldb % 4 != 0) { set_error("%s: reduction dim %lld must be a multiple of 4", what, (long long)K); return TOAD_ESHAPE; }
+    if (!aligned16(A) || !aligned16(B) || !aligned16(C)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_SMEM);
+        attr_set = true;
+    }
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+    const int grid = kNumXCD * ((tiles_m + kNumXCD - 1) / kNumXCD) * tiles_n;
+    hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3(grid), dim3(256), NT_SMEM, st, A, lda, B, ldb, C, ldc, (int)M, (int)N,
+                       (int)K, bias, relu, addend, mask_src, tiles_m, tiles_n);
+    return check_launch(what);
+}
+
+struct WgradPlan { int nsplit, rows_per_split, tiles_i, tiles_j; };
+static WgradPlan wgrad_plan(int64_t M, int64_t N, int64_t K) {
+    WgradPlan p;
+    p.tiles_i = (int)((N + BM - 1) / BM);
+    p.tiles_j = (int)((K + BN - 1) / BN);
+    const int tiles = p.tiles_i * p.tiles_j;
+    // aim at ~2 blocks per CU (512 blocks), at least 8 reduction steps (256 rows) per split
+    int want = (512 + tiles - 1) / tiles;
+    int64_t maxs = (M + 255) / 256;
+    int ns = (int)(want < maxs ? want : maxs);
+    if (ns < 1) ns = 1;
+    int64_t rps = (M + ns - 1) / ns;
+    rps = (rps + BK - 1) / BK * BK;
+    p.rows_per_split = (int)rps;
+    p.nsplit = (int)((M + rps - 1) / rps);
+    return p;
+}
+
+}  // namespace toad
+
+using namespace toad;
+
+extern "C" int toad_linear_act_fwd_f32(const float *X, const float *W, const float *bias, float *Y, int64_t M,
+                                        int64_t K, int64_t N, int act, void *stream) {
+    if (!X || !W || !Y) { set_error("toad_linear_act_fwd_f32: null pointer"); return TOAD_EINVAL; }
+    if (act != TOAD_ACT_NONE && act != TOAD_ACT_RELU) { set_error("toad_linear_act_fwd_f32: bad act %d", act); return TOAD_EINVAL; }
+    return launch_nt(X, K, W, K, Y, N, M, N, K, bias, act == TOAD_ACT_RELU, nullptr, nullptr, (hipStream_t)stream,
+                     "toad_linear_act_fwd_f32");
+}
+
+extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend, const float *relu_src,
+                                      float *dX, int64_t M, int64_t N, int64_t K, void *stream) {
+    if (!dY || !WT || !dX) { set_error("toad_linear_dgrad_f32: null pointer"); return TOAD_EINVAL; }
+    // dX[M,K] = dY[M,N] . WT[K,N]^T : an NT product with reduction dim N
+    return launch_nt(dY, N, WT, N, dX, K, M, K, N, nullptr, 0, addend, relu_src, (hipStream_t)stream,
+                     "toad_linear_dgrad_f32");
+}
+
+extern "C" size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const WgradPlan p = wgrad_plan(M, N, K);
+    return (size_t)p.nsplit * (size_t)(N * K + N) * sizeof(float);
+}
+
+extern "C" int toad_linear_wgrad_f32(const float *dY, const float *X, float *dW, float *db, int64_t M, int64_t N,
+                                      int64_t K, float beta, void *ws, size_t ws_bytes, void *stream) {
+    const char *what = "toad_linear_wgrad_f32";
+    if (!dY || !X || !dW || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (M <= 0 || N <= 0 || K <= 0) { set_error("%s: non-positive dimension", what); return TOAD_EINVAL; }
+    if (N % 4 != 0 || K % 4 != 0) { set_error("%s: N and K must be multiples of 4", what); return TOAD_ESHAPE; }
+    if (M > INT32_MAX - 4096) { set_error("%s: M too large", what); return TOAD_ESHAPE; }
+    if (!aligned16(dY) || !aligned16(X) || !aligned16(dW) || !aligned16(ws)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (ws_bytes < toad_linear_wgrad_ws_bytes(M, N, K)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN_SMEM);
+        attr_set = true;
+    }
+    const WgradPlan p = wgrad_plan(M, N, K);
+    float *slab = (float *)ws;
+    float *cs = db ? slab + (size_t)p.nsplit * N * K : nullptr;
+    const int tiles = p.tiles_i * p.tiles_j;
+    const int grid = kNumXCD * ((p.nsplit + kNumXCD - 1) / kNumXCD) * tiles;
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(grid), dim3(256), TN_SMEM, st, dY, N, X, K, slab, cs, (int)M, (int)N,
+                       (int)K, p.rows_per_split, p.tiles_i, p.tiles_j, p.nsplit);
+    int rc = check_launch(what);
+    if (rc) return rc;
+    const int64_t n = N * K;
+    int rgrid = (int)((n / 4 + 255) / 256);
+    if (rgrid > 2048) rgrid = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, st, slab, dW, n, p.nsplit, beta);
+    rc = check_launch(what);
+    if (rc) return rc;
+    if (db) {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)((N / 4 + 255) / 256)), dim3(256), 0, st, cs, db, N, p.nsplit, beta);
+        rc = check_launch(what);
+    }
+    return rc;
+}
+
+extern "C" int toad_transpose_f32(const float *in, float *out, int64_t rows, int64_t cols, void *stream) {
+    if (!in || !out || rows <= 0 || cols <= 0) { set_error("toad_transpose_f32: bad argument"); return TOAD_EINVAL; }
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, (int)rows, (int)cols);
+    return check_launch("toad_transpose_f32");
+}

@@ -1,0 +1,164 @@
+// heads.hip — the two classifier heads of TOAD_fc_mtl_concat and the caller's weighted CE.
+//
+// models/model_toad.py:99-107 (concat sex, Linear(513,C), Linear(513,2), topk, softmax) and
+// utils/core_utils_mtl_concat.py:213-215 (0.75*CE + 0.25*CE).  O(10 kFLOP) per slide: these
+// kernels exist to keep the per-slide tail at three launches, not for throughput.
+#include "common.h"
+
+#include <math.h>
+
+namespace toad {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// softmax + first-argmax of n logits by one wave
+__device__ void wave_softmax_argmax(const float *lg, int n, float *prob, int64_t *hat, int lane) {
+    float mx = -INFINITY;
+    for (int i = lane; i < n; i += 64) mx = fmaxf(mx, lg[i]);
+    mx = wave_max(mx);
+    int best = INT32_MAX;
+    for (int i = lane; i < n; i += 64)
+        if (lg[i] == mx && i < best) best = i;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += expf(lg[i] - mx);
+    s = wave_sum(s);
+    for (int i = lane; i < n; i += 64) prob[i] = expf(lg[i] - mx) / s;
+    if (lane == 0) *hat = best == INT32_MAX ? 0 : best;
+}
+
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float *__restrict__ M, const float *__restrict__ sex,
+                                                         const float *__restrict__ Wcls, const float *__restrict__ bcls,
+                                                         const float *__restrict__ Wsite, const float *__restrict__ bsite,
+                                                         float *Mcat, float *logits, float *Y_prob, int64_t *Y_hat,
+                                                         float *site_logits, float *site_prob, int64_t *site_hat, int L,
+                                                         int C) {
+    extern __shared__ float s_m[];   // [2][L+1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int LP = L + 1;
+    const float sx = sex[0];
+    for (int e = tid; e < 2 * LP; e += 256) {
+        const int t = e / LP, k = e % LP;
+        const float v = k < L ? M[t * L + k] : sx;
+        s_m[e] = v;
+        Mcat[e] = v;
+    }
+    __syncthreads();
+    // rows 0..C-1: classifier on Mcat[0]; rows C, C+1: site classifier on Mcat[1]
+    for (int r = wave; r < C + 2; r += 4) {
+        const float *w = r < C ? Wcls + (int64_t)r * LP : Wsite + (int64_t)(r - C) * LP;
+        const float *x = r < C ? s_m : s_m + LP;
+        float p = 0.f;
+        for (int k = lane; k < LP; k += 64) p = fmaf(w[k], x[k], p);
+        p = wave_sum(p);
+        if (lane == 0) {
+            if (r < C) logits[r] = p + bcls[r];
+            else site_logits[r - C] = p + bsite[r - C];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) wave_softmax_argmax(logits, C, Y_prob, Y_hat, lane);
+    if (wave == 1) wave_softmax_argmax(site_logits, 2, site_prob, site_hat, lane);
+}
+
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const float *__restrict__ Mcat, const float *__restrict__ dlogits,
+                                                         const float *__restrict__ dsite, const float *__restrict__ Wcls,
+                                                         const float *__restrict__ Wsite, const float *__restrict__ dMcat_ext,
+                                                         float *dWcls, float *dbcls, float *dWsite, float *dbsite,
+                                                         float *dM, float beta, int L, int C) {
+    const int LP = L + 1;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= LP) return;
+    const float x0 = Mcat[k], x1 = Mcat[LP + k];
+    float d0 = 0.f, d1 = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float g = dlogits[c];
+        const int64_t o = (int64_t)c * LP + k;
+        dWcls[o] = (beta != 0.f ? beta * dWcls[o] : 0.f) + g * x0;
+        d0 = fmaf(g, Wcls[o], d0);
+    }
+    for (int c = 0; c < 2; ++c) {
+        const float g = dsite[c];
+        const int o = c * LP + k;
+        dWsite[o] = (beta != 0.f ? beta * dWsite[o] : 0.f) + g * x1;
+        d1 = fmaf(g, Wsite[o], d1);
+    }
+    if (k < L) {
+        dM[k] = d0 + (dMcat_ext ? dMcat_ext[k] : 0.f);
+        dM[L + k] = d1 + (dMcat_ext ? dMcat_ext[LP + k] : 0.f);
+    }
+    if (k < C) dbcls[k] = (beta != 0.f ? beta * dbcls[k] : 0.f) + dlogits[k];
+    if (k < 2) dbsite[k] = (beta != 0.f ? beta * dbsite[k] : 0.f) + dsite[k];
+}
+
+// one wave: loss and d loss / d logits for w_cls*CE(logits,label) + w_site*CE(site_logits,site)
+__device__ float wave_ce(const float *lg, int n, int64_t y, float wgt, float *dlg, int lane) {
+    float mx = -INFINITY;
+    for (int i = lane; i < n; i += 64) mx = fmaxf(mx, lg[i]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += expf(lg[i] - mx);
+    s = wave_sum(s);
+    for (int i = lane; i < n; i += 64) dlg[i] = wgt * (expf(lg[i] - mx) / s - (i == (int)y ? 1.f : 0.f));
+    return (logf(s) + mx) - lg[y];
+}
+__global__ __launch_bounds__(64) void mtl_ce_kernel(const float *logits, const float *site_logits, const int64_t *label,
+                                                     const int64_t *site, float w_cls, float w_site, float *loss_out,
+                                                     float *dlogits, float *dsite, int C) {
+    const int lane = threadIdx.x;
+    const float lc = wave_ce(logits, C, label[0], w_cls, dlogits, lane);
+    const float ls = wave_ce(site_logits, 2, site[0], w_site, dsite, lane);
+    if (lane == 0) {
+        loss_out[0] = w_cls * lc + w_site * ls;
+        loss_out[1] = lc;
+        loss_out[2] = ls;
+    }
+}
+
+}  // namespace toad
+
+using namespace toad;
+
+extern "C" int toad_heads_fwd_f32(const float *M, const float *sex, const float *Wcls, const float *bcls,
+                                   const float *Wsite, const float *bsite, float *Mcat, float *logits, float *Y_prob,
+                                   int64_t *Y_hat, float *site_logits, float *site_prob, int64_t *site_hat, int L, int C,
+                                   void *stream) {
+    const char *what = "toad_heads_fwd_f32";
+    if (!M || !sex || !Wcls || !bcls || !Wsite || !bsite || !Mcat || !logits || !Y_prob || !Y_hat || !site_logits || !site_prob || !site_hat) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (L <= 0 || L > 8192 || C <= 0 || C > 1024) { set_error("%s: unsupported L=%d C=%d", what, L, C); return TOAD_ESHAPE; }
+    hipLaunchKernelGGL(heads_fwd_kernel, dim3(1), dim3(256), 2 * (L + 1) * sizeof(float), (hipStream_t)stream, M, sex, Wcls,
+                       bcls, Wsite, bsite, Mcat, logits, Y_prob, Y_hat, site_logits, site_prob, site_hat, L, C);
+    return check_launch(what);
+}
+
+extern "C" int toad_heads_bwd_f32(const float *Mcat, const float *dlogits, const float *dsite, const float *Wcls,
+                                   const float *Wsite, const float *dMcat_ext, float *dWcls, float *dbcls, float *dWsite,
+                                   float *dbsite, float *dM, float beta, int L, int C, void *stream) {
+    const char *what = "toad_heads_bwd_f32";
+    if (!Mcat || !dlogits || !dsite || !Wcls || !Wsite || !dWcls || !dbcls || !dWsite || !dbsite || !dM) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (L <= 0 || L > 8192 || C <= 0 || C > 1024 || C > L) { set_error("%s: unsupported L=%d C=%d", what, L, C); return TOAD_ESHAPE; }
+    hipLaunchKernelGGL(heads_bwd_kernel, dim3((L + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, Mcat, dlogits, dsite,
+                       Wcls, Wsite, dMcat_ext, dWcls, dbcls, dWsite, dbsite, dM, beta, L, C);
+    return check_launch(what);
+}
+
+extern "C" int toad_mtl_ce_fwd_bwd_f32(const float *logits, const float *site_logits, const int64_t *label,
+                                        const int64_t *site, float w_cls, float w_site, float *loss_out, float *dlogits,
+                                        float *dsite, int C, void *stream) {
+    const char *what = "toad_mtl_ce_fwd_bwd_f32";
+    if (!logits || !site_logits || !label || !site || !loss_out || !dlogits || !dsite) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (C <= 0 || C > 1024) { set_error("%s: unsupported C=%d", what, C); return TOAD_ESHAPE; }
+    hipLaunchKernelGGL(mtl_ce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, logits, site_logits, label, site, w_cls,
+                       w_site, loss_out, dlogits, dsite, C);
+    return check_launch(what);
+}

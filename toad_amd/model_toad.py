@@ -1,0 +1,229 @@
+"""MI355X-native drop-in for the reference's ``models/model_toad.py``.
+
+Same public surface as the reference (so ``utils/core_utils_mtl_concat.py`` /
+``utils/eval_utils_mtl_concat.py`` can ``from models.model_toad import TOAD_fc_mtl_concat``
+unchanged — INTEGRATION.md):
+
+  * ``Attn_Net_Gated(L=1024, D=256, dropout=False, n_tasks=1)``          (model_toad.py:17-41)
+  * ``TOAD_fc_mtl_concat(gate=True, size_arg="big", dropout=False, n_classes=2)`` with
+    ``relocate()`` and ``forward(h, sex, return_features=False, attention_only=False)``
+    returning the same result dict                                         (model_toad.py:53-116)
+  * identical sub-module layout, hence identical ``state_dict()`` keys/shapes
+  * Xavier-normal weights / zero biases at construction                    (utils/utils.py:150-154)
+
+What differs is everything underneath: ``forward`` never calls the nn.Linear/Tanh/Sigmoid
+sub-modules (they only own the parameters); it runs hand-written gfx950 kernels from
+libtoad_hip.so through ``toad_amd.functional``.  There is no CPU path — CPU tensors raise.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+from . import ops
+
+_ALIGN = 64  # floats (256 B): every parameter starts 256-B aligned inside the flat buffer
+
+
+def initialize_weights(module: nn.Module) -> None:
+    """Same initialisation as the reference's utils/utils.py:150-154."""
+    for m in module.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_normal_(m.weight)
+            m.bias.data.zero_()
+
+
+def _require_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} is on {t.device}: toad_amd runs on MI355X (HIP) only and has no CPU fallback. "
+            "Call model.relocate() and move the inputs to the GPU.")
+
+
+class _ScoresFn(torch.autograd.Function):
+    """Standalone Attn_Net_Gated: A = (tanh(xWa^T+ba) * sigmoid(xWb^T+bb)) Wc^T + bc."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ba, wb, bb, wc, bc):
+        wab, bab = torch.cat([wa, wb], 0), torch.cat([ba, bb], 0)
+        p = ops.linear_act_fwd(x, wab, bab, ops.ACT_NONE)
+        a_raw, _, _ = ops.gated_pool_fwd(p, wa.shape[0], None, wc, bc)
+        ctx.save_for_backward(x, p, wab, wc)
+        ctx.need_dx = x.requires_grad
+        return a_raw
+
+    @staticmethod
+    def backward(ctx, da):
+        x, p, wab, wc = ctx.saved_tensors
+        d, t = wc.shape[1], wc.shape[0]
+        n, l = x.shape
+        dev = x.device
+        # reuse the pooled backward with softmax weight p == 0 (stats = (0, inf)): dS = dA
+        stats = torch.tensor([[0.0, float("inf")]] * t, device=dev)
+        zeros = torch.zeros((t, l), device=dev)
+        dp, _, dwc, dbc = ops.gated_pool_bwd(p, d, x, wc, torch.zeros((n, t), device=dev), stats, zeros, zeros,
+                                             da.contiguous())
+        dwab, dbab = ops.linear_wgrad(dp, x)
+        dx = ops.linear_dgrad(dp, ops.transpose(wab)) if ctx.need_dx else None
+        return dx, dwab[:d], dbab[:d], dwab[d:], dbab[d:], dwc, dbc
+
+
+class Attn_Net_Gated(nn.Module):
+    """Attention network with sigmoid gating (3 fc layers) — reference models/model_toad.py:17-41."""
+
+    def __init__(self, L: int = 1024, D: int = 256, dropout: bool = False, n_tasks: int = 1):
+        super().__init__()
+        a = [nn.Linear(L, D), nn.Tanh()]
+        b = [nn.Linear(L, D), nn.Sigmoid()]
+        if dropout:
+            a.append(nn.Dropout(0.25))
+            b.append(nn.Dropout(0.25))
+        self.attention_a = nn.Sequential(*a)
+        self.attention_b = nn.Sequential(*b)
+        self.attention_c = nn.Linear(D, n_tasks)
+        self._dropout = bool(dropout)
+
+    def forward(self, x):
+        _require_cuda(x, "x")
+        if self._dropout and self.training:
+            raise NotImplementedError("toad_amd: in-kernel dropout masks are not implemented yet; "
+                                      "use dropout=False or model.eval()")
+        A = _ScoresFn.apply(x.contiguous(), self.attention_a[0].weight, self.attention_a[0].bias,
+                            self.attention_b[0].weight, self.attention_b[0].bias,
+                            self.attention_c.weight, self.attention_c.bias)
+        return A, x
+
+
+class TOAD_fc_mtl_concat(nn.Module):
+    """TOAD multi-task + concat MIL network with attention pooling — reference models/model_toad.py:53-116."""
+
+    def __init__(self, gate: bool = True, size_arg: str = "big", dropout: bool = False, n_classes: int = 2):
+        super().__init__()
+        self.size_dict = {"small": [1024, 512, 256], "big": [1024, 512, 384]}
+        size = self.size_dict[size_arg]
+        if not gate:
+            # the reference refers to an undefined Attn_Net here (model_toad.py:68 -> NameError)
+            raise NameError("name 'Attn_Net' is not defined (gate=False is not supported by the reference either)")
+        fc = [nn.Linear(size[0], size[1]), nn.ReLU()]
+        if dropout:
+            fc.append(nn.Dropout(0.25))
+        fc.extend([nn.Linear(size[1], size[1]), nn.ReLU()])
+        if dropout:
+            fc.append(nn.Dropout(0.25))
+        fc.append(Attn_Net_Gated(L=size[1], D=size[2], dropout=dropout, n_tasks=2))
+        self.attention_net = nn.Sequential(*fc)
+        self.classifier = nn.Linear(size[1] + 1, n_classes)
+        self.site_classifier = nn.Linear(size[1] + 1, 2)
+        initialize_weights(self)
+        self._dropout = bool(dropout)
+        self._idx2 = 3 if dropout else 2          # position of the second Linear inside attention_net
+        self._flat: Optional[torch.Tensor] = None
+        self._views: Dict[str, torch.Tensor] = {}
+
+    # ---- parameter plumbing ---------------------------------------------------------------
+    def _slot_params(self) -> Dict[str, nn.Parameter]:
+        net = self.attention_net
+        att = net[len(net) - 1]
+        return {
+            "w1": net[0].weight, "b1": net[0].bias,
+            "w2": net[self._idx2].weight, "b2": net[self._idx2].bias,
+            "wa": att.attention_a[0].weight, "ba": att.attention_a[0].bias,
+            "wb": att.attention_b[0].weight, "bb": att.attention_b[0].bias,
+            "wc": att.attention_c.weight, "bc": att.attention_c.bias,
+            "wcls": self.classifier.weight, "bcls": self.classifier.bias,
+            "wsite": self.site_classifier.weight, "bsite": self.site_classifier.bias,
+        }
+
+    # flat layout: Wa|Wb and ba|bb adjacent so the stacked 512->768 GEMM is zero-copy
+    _FLAT_ORDER = ("w1", "b1", "w2", "b2", "wa", "wb", "ba", "bb", "wc", "bc", "wcls", "bcls", "wsite", "bsite")
+
+    def _flat_layout(self):
+        sp = self._slot_params()
+        offs, off = {}, 0
+        for k in self._FLAT_ORDER:
+            offs[k] = off
+            n = sp[k].numel()
+            adjacent_next = k in ("wa", "ba")        # keep the b-half glued to the a-half
+            off += n if adjacent_next else (n + _ALIGN - 1) // _ALIGN * _ALIGN
+        return sp, offs, off
+
+    def _is_flat(self) -> bool:
+        if self._flat is None:
+            return False
+        sp, offs, _ = self._flat_layout()
+        base = self._flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * offs[k] and p.device == self._flat.device for k, p in sp.items())
+
+    def flatten_parameters(self) -> torch.Tensor:
+        """Re-home every parameter as a view of one contiguous fp32 buffer (values preserved).
+        Makes [Wa;Wb] a zero-copy view and gives data-parallel training one all-reduce bucket."""
+        sp, offs, total = self._flat_layout()
+        dev = sp["w1"].device
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for k, p in sp.items():
+                v = flat[offs[k]: offs[k] + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+        self._flat = flat
+        d, l = sp["wa"].shape
+        self._views = {
+            "wab": flat[offs["wa"]: offs["wa"] + 2 * d * l].view(2 * d, l),
+            "bab": flat[offs["ba"]: offs["ba"] + 2 * d],
+        }
+        return flat
+
+    def flat_parameters(self) -> torch.Tensor:
+        if not self._is_flat():
+            self.flatten_parameters()
+        return self._flat
+
+    def flat_offsets(self):
+        sp, offs, total = self._flat_layout()
+        return {k: (offs[k], sp[k].numel()) for k in sp}, total
+
+    def _weights(self) -> Dict[str, torch.Tensor]:
+        if not self._is_flat():
+            self.flatten_parameters()
+        w: Dict[str, torch.Tensor] = dict(self._slot_params())
+        w.update(self._views)
+        return w
+
+    # ---- reference API --------------------------------------------------------------------
+    def relocate(self):
+        """Reference: models/model_toad.py:77-88. Places the model on the current HIP device.
+        Never wraps in nn.DataParallel: one process drives one GPU; slides, not patches, are
+        sharded across GPUs (toad_amd.dp)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("toad_amd.relocate(): no HIP device visible; this package has no CPU fallback")
+        device = torch.device("cuda", torch.cuda.current_device())
+        self.to(device)
+        self.flatten_parameters()
+
+    def forward(self, h, sex, return_features=False, attention_only=False):
+        _require_cuda(h, "h")
+        if self._dropout and self.training:
+            raise NotImplementedError("toad_amd: in-kernel dropout masks are not implemented yet; "
+                                      "use dropout=False or model.eval()")
+        w = self._weights()
+        _require_cuda(w["w1"], "model parameters")
+        h = h.contiguous()
+        if attention_only:
+            with torch.no_grad():
+                a_raw = F_.attention_scores({k: v.detach() for k, v in w.items()}, h)
+            return a_raw.t()[0]                                   # model_toad.py:92-94: raw task-0 scores, [N]
+        _require_cuda(sex, "sex")
+        sex = sex.to(torch.float32).reshape(1).contiguous()
+        sp = [w[k] for k in F_.SLOTS]
+        logits, site_logits, a_nt, feats, y_prob, y_hat, site_prob, site_hat = F_.ToadMIL.apply(
+            h, sex, *sp, w["wab"], w["bab"])
+        results_dict = {}
+        if return_features:
+            results_dict.update({"features": feats})              # M after the sex concat, [2, L+1]
+        results_dict.update({"logits": logits, "Y_prob": y_prob, "Y_hat": y_hat,
+                             "site_logits": site_logits, "site_prob": site_prob, "site_hat": site_hat,
+                             "A": a_nt.t()})                      # pre-softmax scores, [2, N] (transpose view)
+        return results_dict

@@ -1,0 +1,214 @@
+"""Thin tensor-level wrappers over the C ABI (pointers + sizes + the current HIP stream).
+
+PyTorch is used for device memory and streams only; all arithmetic happens in libtoad_hip.so.
+Shape/dtype/device/contiguity are validated here (the checks PyTorch's own ops would do for the
+reference), the C side validates again and reports through toad_last_error().
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU = 0, 1
+
+
+def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32, allow_none: bool = False):
+    if t is None:
+        if allow_none:
+            return
+        raise ValueError(f"{name} is None")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA(HIP) tensor: toad_amd has no CPU path (got {t.device})")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def linear_act_fwd(x, w, b, act: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Y = act(X W^T + b); X [M,K], W [N,K], b [N] or None."""
+    _chk(x, "x"); _chk(w, "w"); _chk(b, "b", allow_none=True)
+    m, k = x.shape
+    n, k2 = w.shape
+    if k != k2 or (b is not None and b.numel() != n):
+        raise ValueError(f"linear_act_fwd: shape mismatch x{tuple(x.shape)} w{tuple(w.shape)}")
+    y = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=x.device)
+    _chk(y, "out")
+    lib = _lib.load()
+    _lib.check(lib.toad_linear_act_fwd_f32(_p(x), _p(w), _p(b), _p(y), m, k, n, act, _stream()), "toad_linear_act_fwd_f32")
+    return y
+
+
+def transpose(w: torch.Tensor) -> torch.Tensor:
+    _chk(w, "w")
+    r, c = w.shape
+    out = torch.empty((c, r), dtype=torch.float32, device=w.device)
+    _lib.check(_lib.load().toad_transpose_f32(_p(w), _p(out), r, c, _stream()), "toad_transpose_f32")
+    return out
+
+
+def linear_dgrad(dy, wt, addend=None, relu_src=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dX = (dY W + addend) * (relu_src > 0); dY [M,N], wt = W^T [K,N]."""
+    _chk(dy, "dy"); _chk(wt, "wt"); _chk(addend, "addend", allow_none=True); _chk(relu_src, "relu_src", allow_none=True)
+    m, n = dy.shape
+    k, n2 = wt.shape
+    if n != n2:
+        raise ValueError("linear_dgrad: shape mismatch")
+    dx = out if out is not None else torch.empty((m, k), dtype=torch.float32, device=dy.device)
+    _chk(dx, "out")
+    for t, nm in ((addend, "addend"), (relu_src, "relu_src"), (dx, "out")):
+        if t is not None and tuple(t.shape) != (m, k):
+            raise ValueError(f"linear_dgrad: {nm} must be [{m},{k}]")
+    _lib.check(_lib.load().toad_linear_dgrad_f32(_p(dy), _p(wt), _p(addend), _p(relu_src), _p(dx), m, n, k, _stream()),
+               "toad_linear_dgrad_f32")
+    return dx
+
+
+def linear_wgrad(dy, x, dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None,
+                 beta: float = 0.0, want_db: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """dW = beta*dW + dY^T X; db = beta*db + colsum(dY)."""
+    _chk(dy, "dy"); _chk(x, "x")
+    m, n = dy.shape
+    m2, k = x.shape
+    if m != m2:
+        raise ValueError("linear_wgrad: shape mismatch")
+    if dw is None:
+        dw = torch.empty((n, k), dtype=torch.float32, device=dy.device); beta = 0.0
+    if db is None and want_db:
+        db = torch.empty((n,), dtype=torch.float32, device=dy.device)
+    _chk(dw, "dw"); _chk(db, "db", allow_none=True)
+    lib = _lib.load()
+    nbytes = lib.toad_linear_wgrad_ws_bytes(m, n, k)
+    ws = _ws(nbytes, dy.device)
+    _lib.check(lib.toad_linear_wgrad_f32(_p(dy), _p(x), _p(dw), _p(db), m, n, k, float(beta), _p(ws), ws.numel(), _stream()),
+               "toad_linear_wgrad_f32")
+    return dw, db
+
+
+def gated_pool_fwd(p: torch.Tensor, d: int, h: Optional[torch.Tensor], wc, bc):
+    """p = [N, 2D] stacked pre-activations (Pa | Pb). Returns (A_raw [N,T], M [T,L], stats [T,2]);
+    with h=None only A_raw is computed (attention_only)."""
+    _chk(p, "p"); _chk(h, "h", allow_none=True); _chk(wc, "wc"); _chk(bc, "bc")
+    n, ldp = p.shape
+    t = wc.shape[0]
+    if ldp != 2 * d or wc.shape[1] != d or bc.numel() != t:
+        raise ValueError("gated_pool_fwd: shape mismatch")
+    lib = _lib.load()
+    a_raw = torch.empty((n, t), dtype=torch.float32, device=p.device)
+    pb_ptr = p.data_ptr() + 4 * d
+    if h is None:
+        _lib.check(lib.toad_gated_pool_fwd_f32(_p(p), pb_ptr, ldp, None, _p(wc), _p(bc), _p(a_raw), None, None, None, 0,
+                                               n, 512, d, t, _stream()), "toad_gated_pool_fwd_f32")
+        return a_raw, None, None
+    l = h.shape[1]
+    if h.shape[0] != n:
+        raise ValueError("gated_pool_fwd: h rows != p rows")
+    m = torch.empty((t, l), dtype=torch.float32, device=p.device)
+    stats = torch.empty((t, 2), dtype=torch.float32, device=p.device)
+    ws = _ws(lib.toad_gated_pool_ws_bytes(n, l, d, t), p.device)
+    _lib.check(lib.toad_gated_pool_fwd_f32(_p(p), pb_ptr, ldp, _p(h), _p(wc), _p(bc), _p(a_raw), _p(m), _p(stats),
+                                           _p(ws), ws.numel(), n, l, d, t, _stream()), "toad_gated_pool_fwd_f32")
+    return a_raw, m, stats
+
+
+def gated_pool_bwd(p, d: int, h, wc, a_raw, stats, m, dm, da_ext=None, dwc=None, dbc=None, beta: float = 0.0,
+                   dp: Optional[torch.Tensor] = None, dh: Optional[torch.Tensor] = None):
+    """Returns (dP [N,2D], dH_pool [N,L], dWc [T,D], dbc [T])."""
+    for t_, nm in ((p, "p"), (h, "h"), (wc, "wc"), (a_raw, "a_raw"), (stats, "stats"), (m, "m"), (dm, "dm")):
+        _chk(t_, nm)
+    _chk(da_ext, "da_ext", allow_none=True)
+    n, ldp = p.shape
+    l = h.shape[1]
+    t = wc.shape[0]
+    if ldp != 2 * d or tuple(a_raw.shape) != (n, t) or tuple(dm.shape) != (t, l) or tuple(m.shape) != (t, l):
+        raise ValueError("gated_pool_bwd: shape mismatch")
+    if dp is None:
+        dp = torch.empty_like(p)
+    if dh is None:
+        dh = torch.empty_like(h)
+    if dwc is None:
+        dwc = torch.empty_like(wc); dbc = torch.empty((t,), dtype=torch.float32, device=p.device); beta = 0.0
+    _chk(dp, "dp"); _chk(dh, "dh"); _chk(dwc, "dwc"); _chk(dbc, "dbc")
+    lib = _lib.load()
+    ws = _ws(lib.toad_gated_pool_bwd_ws_bytes(n, l, d, t), p.device)
+    _lib.check(lib.toad_gated_pool_bwd_f32(_p(p), p.data_ptr() + 4 * d, ldp, _p(h), _p(wc), _p(a_raw), _p(stats), _p(m),
+                                           _p(dm), _p(da_ext), _p(dp), dp.data_ptr() + 4 * d, ldp, _p(dh), _p(dwc),
+                                           _p(dbc), float(beta), _p(ws), ws.numel(), n, l, d, t, _stream()),
+               "toad_gated_pool_bwd_f32")
+    return dp, dh, dwc, dbc
+
+
+def heads_fwd(m, sex, wcls, bcls, wsite, bsite):
+    """Returns (Mcat [2,L+1], logits [1,C], Y_prob, Y_hat [1,1] int64, site_logits [1,2], site_prob, site_hat)."""
+    for t_, nm in ((m, "m"), (sex, "sex"), (wcls, "wcls"), (bcls, "bcls"), (wsite, "wsite"), (bsite, "bsite")):
+        _chk(t_, nm)
+    l = m.shape[1]
+    c = wcls.shape[0]
+    if m.shape[0] != 2 or wcls.shape[1] != l + 1 or tuple(wsite.shape) != (2, l + 1) or sex.numel() != 1:
+        raise ValueError("heads_fwd: shape mismatch")
+    dev = m.device
+    mcat = torch.empty((2, l + 1), dtype=torch.float32, device=dev)
+    logits = torch.empty((1, c), dtype=torch.float32, device=dev)
+    y_prob = torch.empty((1, c), dtype=torch.float32, device=dev)
+    y_hat = torch.empty((1, 1), dtype=torch.int64, device=dev)
+    site_logits = torch.empty((1, 2), dtype=torch.float32, device=dev)
+    site_prob = torch.empty((1, 2), dtype=torch.float32, device=dev)
+    site_hat = torch.empty((1, 1), dtype=torch.int64, device=dev)
+    _lib.check(_lib.load().toad_heads_fwd_f32(_p(m), _p(sex), _p(wcls), _p(bcls), _p(wsite), _p(bsite), _p(mcat), _p(logits),
+                                              _p(y_prob), _p(y_hat), _p(site_logits), _p(site_prob), _p(site_hat), l, c,
+                                              _stream()), "toad_heads_fwd_f32")
+    return mcat, logits, y_prob, y_hat, site_logits, site_prob, site_hat
+
+
+def heads_bwd(mcat, dlogits, dsite, wcls, wsite, dmcat_ext=None, grads=None, beta: float = 0.0):
+    """Returns (dWcls, dbcls, dWsite, dbsite, dM [2,L]). grads = optional tuple of 4 destination tensors."""
+    for t_, nm in ((mcat, "mcat"), (dlogits, "dlogits"), (dsite, "dsite"), (wcls, "wcls"), (wsite, "wsite")):
+        _chk(t_, nm)
+    _chk(dmcat_ext, "dmcat_ext", allow_none=True)
+    l = mcat.shape[1] - 1
+    c = wcls.shape[0]
+    dev = mcat.device
+    if dlogits.numel() != c or dsite.numel() != 2:
+        raise ValueError("heads_bwd: shape mismatch")
+    if grads is None:
+        grads = (torch.empty_like(wcls), torch.empty((c,), dtype=torch.float32, device=dev),
+                 torch.empty_like(wsite), torch.empty((2,), dtype=torch.float32, device=dev))
+        beta = 0.0
+    dwcls, dbcls, dwsite, dbsite = grads
+    for t_, nm in ((dwcls, "dwcls"), (dbcls, "dbcls"), (dwsite, "dwsite"), (dbsite, "dbsite")):
+        _chk(t_, nm)
+    dm = torch.empty((2, l), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().toad_heads_bwd_f32(_p(mcat), _p(dlogits), _p(dsite), _p(wcls), _p(wsite), _p(dmcat_ext),
+                                              _p(dwcls), _p(dbcls), _p(dwsite), _p(dbsite), _p(dm), float(beta), l, c,
+                                              _stream()), "toad_heads_bwd_f32")
+    return dwcls, dbcls, dwsite, dbsite, dm
+
+
+def mtl_ce_fwd_bwd(logits, site_logits, label, site, w_cls: float = 0.75, w_site: float = 0.25):
+    """Weighted two-task CE and its gradient. Returns (loss_vec[3] = loss, cls_loss, site_loss; dlogits; dsite)."""
+    _chk(logits, "logits"); _chk(site_logits, "site_logits")
+    _chk(label, "label", dtype=torch.int64); _chk(site, "site", dtype=torch.int64)
+    c = logits.numel()
+    dev = logits.device
+    loss = torch.empty((3,), dtype=torch.float32, device=dev)
+    dlogits = torch.empty((1, c), dtype=torch.float32, device=dev)
+    dsite = torch.empty((1, 2), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().toad_mtl_ce_fwd_bwd_f32(_p(logits), _p(site_logits), _p(label), _p(site), float(w_cls),
+                                                   float(w_site), _p(loss), _p(dlogits), _p(dsite), c, _stream()),
+               "toad_mtl_ce_fwd_bwd_f32")
+    return loss, dlogits, dsite
