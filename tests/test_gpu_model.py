@@ -40,6 +40,28 @@ def test_module_matches_reference_golden(cuda, golden, name):
     assert torch.equal(a_only, res["A"][0].detach())
 
 
+@pytest.mark.parametrize("name", ["n777", "n1024_sat", "n10000"])
+def test_backward_chain_tight_with_identical_relu_masks(cuda, golden, name):
+    """Flip-free check of the whole backward chain: the oracle's hand-written backward is run on
+    the activations the GPU forward saved (so ReLU masks are identical on both sides); what is left
+    is rounding only, so the bound is 2e-5 of each gradient's own scale."""
+    from toad_amd import functional as F_
+    ci = case_inputs(golden, name)
+    w = {s: ci["params"][k].to(cuda) for s, k in SLOT2KEY.items()}
+    outs, sv = F_.mil_forward(w, ci["x"].to(cuda), ci["sex"].to(cuda))
+    dl, ds = orc.loss_grad(outs["logits"].cpu(), ci["label"], outs["site_logits"].cpu(), ci["site"])
+    g, _ = F_.mil_backward(w, sv, dl.to(cuda), ds.to(cuda))
+    saved_cpu = orc.Saved(x=ci["x"], h1=sv.h1.cpu(), h=sv.h.cpu(), p=sv.p.cpu(), a_raw=sv.a_raw.cpu(),
+                          m=sv.m.cpu(), mcat=sv.mcat.cpu(), sex=ci["sex"])
+    og = orc.backward({k: v.double() for k, v in ci["params"].items()},
+                      orc.Saved(**{k: (v.double() if v.is_floating_point() else v) for k, v in saved_cpu.__dict__.items()}),
+                      dl.double(), ds.double())
+    for sl, k in SLOT2KEY.items():
+        ref = og[k]
+        err = (g[sl].cpu().double() - ref).abs().max().item()
+        assert err <= 2e-5 * max(ref.abs().max().item(), 1e-4) + 1e-9, (name, sl, err, ref.abs().max().item())
+
+
 def test_module_random_bag_vs_oracle(cuda):
     torch.manual_seed(0)
     from toad_amd import TOAD_fc_mtl_concat
@@ -79,8 +101,8 @@ def test_fused_loss_path_equals_autograd_path(cuda):
     lossv, dl, ds = ops.mtl_ce_fwd_bwd(outs["logits"], outs["site_logits"], label, site)
     g, _ = F_.mil_backward(w, saved, dl, ds)
     sp = model._slot_params()
-    for k in F_.SLOTS:
-        assert torch.equal(g[k], sp[k].grad), k            # same kernels, same order -> bitwise
+    for k in F_.SLOTS:      # same kernels; only d(loss)/d(logits) comes from a different CE implementation
+        assert (g[k] - sp[k].grad).abs().max().item() <= 1e-5 * max(sp[k].grad.abs().max().item(), 1e-3), k
     dest = {k: torch.ones_like(sp[k]) for k in F_.SLOTS}
     g2, _ = F_.mil_backward(w, saved, dl, ds, grads=dest, beta=1.0)
     for k in F_.SLOTS:
