@@ -1,0 +1,186 @@
+"""bench.py — headline benchmark of the TOAD gated-attention MIL hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one optimiser step of slide-sharded data parallel training: every rank runs
+forward + weighted CE + backward over its own synthetic 100,000-patch x 1024-d bag (fp32, already
+resident in HBM), ONE all-reduce of the 4.77 MB flat gradient over RCCL when N > 1, then Adam.
+value = slides/s over the whole job (N slides per step / max-over-ranks step time).  Weak scaling.
+
+The JSON line also carries
+  roofline       the fused gated-attention pooling forward (the kernel BASELINE.json's metric names):
+                 algorithmic bytes 4*[N*(2D+L+T)+T*D+T+T*L] per launch / mean launch time measured
+                 with HIP events on the launch stream inside the timed steps, vs 8 TB/s HBM;
+  roofline_mfma  all eight fp32-MFMA GEMM launches of a step: 6,029,312*N FLOP / their summed
+                 event time, vs the 157.3 TF exact-fp32 MFMA peak;
+  cpu_baseline   the CPU oracle (structurally the reference's PyTorch-CPU op sequence, pinned to the
+                 reference in oracle/pin_against_reference.py) timed on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch
+import torch.distributed as dist
+
+L0, L, D, T, C = 1024, 512, 384, 2, 18
+GEMM_FLOP_PER_PATCH = 6_029_312            # 2,359,296 fwd + 3,670,016 bwd
+HBM_PEAK = 8.0e12                          # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK = 157.3e12                   # exact-fp32 MFMA peak
+
+
+def pool_fwd_bytes(n):                     # 5,128 B/patch + constants
+    return 4 * (n * (2 * D + L + T) + T * D + T + T * L)
+
+
+def cpu_baseline(n_patches: int, budget_s: float = 25.0):
+    """fwd + loss + bwd of the CPU oracle on all host cores; bounded sample (>=1 warm-up + >=2 reps)."""
+    from oracle import toad_oracle as orc       # checker / reported baseline only
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params = orc.xavier_params(C, seed=1)
+    x = torch.randn(n_patches, L0, generator=torch.Generator().manual_seed(1000))
+    sex = torch.tensor([0.0]); label = torch.tensor([0]); site = torch.tensor([0])
+    orc.fwd_bwd(params, x, sex, label, site)    # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_start < budget_s and len(times) < 10):
+        t0 = time.perf_counter()
+        orc.fwd_bwd(params, x, sex, label, site)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    cpu_name = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_name = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    return {"value": round(1.0 / med, 4), "unit": "slides/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} x fwd+loss+bwd of one {n_patches}-patch x 1024-d bag after 1 warm-up, median; "
+                      f"oracle/toad_oracle.py (torch CPU, fp32) on {cpu_name}",
+            "ms_per_slide": round(med * 1e3, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--patches", type=int, default=100_000)
+    ap.add_argument("--slides-per-rank", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from toad_amd import TOAD_fc_mtl_concat, ops
+    from toad_amd.dp import SlideShardedDP
+
+    torch.manual_seed(1)                                   # main_mtl_concat.py:89 default seed
+    model = TOAD_fc_mtl_concat(dropout=False, n_classes=C)
+    model.relocate()
+    model.train()
+    dp = SlideShardedDP(model, lambda ps: torch.optim.Adam(ps, lr=1e-4, weight_decay=1e-5, fused=True))
+
+    n = args.patches
+    spr = args.slides_per_rank
+    nbags = 2                                              # alternate two resident bags per slide slot
+    slides = []
+    for b in range(nbags):
+        per = []
+        for s in range(spr):
+            idx = (rank * spr + s) * nbags + b
+            g = torch.Generator(device=dev).manual_seed(1000 + idx)
+            bag = torch.randn(n, L0, device=dev, generator=g)
+            per.append((bag, torch.tensor([float((idx // 2) % 2)], device=dev),
+                        torch.tensor([idx % C], device=dev), torch.tensor([idx % 2], device=dev)))
+        slides.append(per)
+    global_slides = spr * world
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        dp.step(slides[i % nbags], global_slides)
+    sync()
+    ops.enable_timing(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = dp.step(slides[i % nbags], global_slides)
+    sync()
+    elapsed = time.perf_counter() - t0
+    timing = ops.collect_timing()
+    ops.enable_timing(False)
+    last_loss = float(losses[-1][0].item())
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = global_slides * args.steps / elapsed
+        calls, tot_ms = timing["pool_fwd"]
+        pool_t = tot_ms / calls * 1e-3
+        pool_bw = pool_fwd_bytes(n) / pool_t
+        gemm_ms = sum(timing[k][1] for k in ("gemm_fwd", "gemm_dgrad", "gemm_wgrad"))
+        gemm_launch_sets = timing["gemm_fwd"][0] // 3                   # 3 forward GEMMs per slide
+        gemm_t = gemm_ms / gemm_launch_sets * 1e-3
+        gemm_tf = GEMM_FLOP_PER_PATCH * n / gemm_t
+        out = {
+            "metric": "slides/sec fwd+bwd, 100k-patch x 1024-d bags",
+            "value": round(value, 3), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"TOAD_fc_mtl_concat(big, n_classes=18) fwd + 0.75/0.25 CE + bwd + Adam on "
+                                   f"{spr} x {n}-patch x 1024-d N(0,1) bag per GPU per step, bags resident in HBM",
+                       "patches_per_slide": n, "slides_per_step": global_slides,
+                       "parallelism": f"slide-sharded dp{world}, one {4 * model.flat_parameters().numel() / 1e6:.2f} MB grad all-reduce/step"},
+            "roofline": {"bound": "hbm", "kernel": "gated_pool_fwd_kernel<2,6,8,true> + gated_pool_combine_kernel",
+                         "achieved": round(pool_bw / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(pool_bw / HBM_PEAK, 4), "traffic": None,
+                         "algorithmic_bytes": pool_fwd_bytes(n), "us_per_launch": round(pool_t * 1e6, 2)},
+            "roofline_mfma": {"bound": "mfma", "kernel": "gemm_nt_f32_kernel x5 + gemm_tn_f32_kernel x3 (+slab reduce)",
+                              "achieved": round(gemm_tf / 1e12, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                              "frac": round(gemm_tf / MFMA_F32_PEAK, 4), "traffic": None,
+                              "algorithmic_flops": GEMM_FLOP_PER_PATCH * n, "us_per_slide": round(gemm_t * 1e6, 1)},
+            "op_us_per_slide": {k: round(v[1] / (timing["pool_fwd"][0]) * 1e3, 1) for k, v in timing.items()},
+            "last_loss": round(last_loss, 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n)
+            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

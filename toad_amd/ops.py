@@ -14,6 +14,42 @@ from . import _lib
 
 ACT_NONE, ACT_RELU = 0, 1
 
+# ---- optional per-op HIP-event timing (used by bench.py for the roofline figures) -------------
+# Events are recorded on the stream the kernels are launched on (the current torch stream), so the
+# elapsed time is device time of exactly the launches made by that C-ABI call.
+_TIMING = None
+
+
+def enable_timing(on: bool = True) -> None:
+    global _TIMING
+    _TIMING = {} if on else None
+
+
+def collect_timing():
+    """-> {op name: (calls, total milliseconds)}; synchronises the device."""
+    if _TIMING is None:
+        return {}
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in _TIMING.items()}
+
+
+class _timed:
+    __slots__ = ("name", "e0")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _TIMING is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if _TIMING is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _TIMING.setdefault(self.name, []).append((self.e0, e1))
+
 
 def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32, allow_none: bool = False):
     if t is None:
@@ -50,7 +86,8 @@ def linear_act_fwd(x, w, b, act: int, out: Optional[torch.Tensor] = None) -> tor
     y = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=x.device)
     _chk(y, "out")
     lib = _lib.load()
-    _lib.check(lib.toad_linear_act_fwd_f32(_p(x), _p(w), _p(b), _p(y), m, k, n, act, _stream()), "toad_linear_act_fwd_f32")
+    with _timed("gemm_fwd"):
+        _lib.check(lib.toad_linear_act_fwd_f32(_p(x), _p(w), _p(b), _p(y), m, k, n, act, _stream()), "toad_linear_act_fwd_f32")
     return y
 
 
@@ -74,8 +111,9 @@ def linear_dgrad(dy, wt, addend=None, relu_src=None, out: Optional[torch.Tensor]
     for t, nm in ((addend, "addend"), (relu_src, "relu_src"), (dx, "out")):
         if t is not None and tuple(t.shape) != (m, k):
             raise ValueError(f"linear_dgrad: {nm} must be [{m},{k}]")
-    _lib.check(_lib.load().toad_linear_dgrad_f32(_p(dy), _p(wt), _p(addend), _p(relu_src), _p(dx), m, n, k, _stream()),
-               "toad_linear_dgrad_f32")
+    with _timed("gemm_dgrad"):
+        _lib.check(_lib.load().toad_linear_dgrad_f32(_p(dy), _p(wt), _p(addend), _p(relu_src), _p(dx), m, n, k, _stream()),
+                   "toad_linear_dgrad_f32")
     return dx
 
 
@@ -95,8 +133,9 @@ def linear_wgrad(dy, x, dw: Optional[torch.Tensor] = None, db: Optional[torch.Te
     lib = _lib.load()
     nbytes = lib.toad_linear_wgrad_ws_bytes(m, n, k)
     ws = _ws(nbytes, dy.device)
-    _lib.check(lib.toad_linear_wgrad_f32(_p(dy), _p(x), _p(dw), _p(db), m, n, k, float(beta), _p(ws), ws.numel(), _stream()),
-               "toad_linear_wgrad_f32")
+    with _timed("gemm_wgrad"):
+        _lib.check(lib.toad_linear_wgrad_f32(_p(dy), _p(x), _p(dw), _p(db), m, n, k, float(beta), _p(ws), ws.numel(), _stream()),
+                   "toad_linear_wgrad_f32")
     return dw, db
 
 
@@ -121,8 +160,9 @@ def gated_pool_fwd(p: torch.Tensor, d: int, h: Optional[torch.Tensor], wc, bc):
     m = torch.empty((t, l), dtype=torch.float32, device=p.device)
     stats = torch.empty((t, 2), dtype=torch.float32, device=p.device)
     ws = _ws(lib.toad_gated_pool_ws_bytes(n, l, d, t), p.device)
-    _lib.check(lib.toad_gated_pool_fwd_f32(_p(p), pb_ptr, ldp, _p(h), _p(wc), _p(bc), _p(a_raw), _p(m), _p(stats),
-                                           _p(ws), ws.numel(), n, l, d, t, _stream()), "toad_gated_pool_fwd_f32")
+    with _timed("pool_fwd"):
+        _lib.check(lib.toad_gated_pool_fwd_f32(_p(p), pb_ptr, ldp, _p(h), _p(wc), _p(bc), _p(a_raw), _p(m), _p(stats),
+                                               _p(ws), ws.numel(), n, l, d, t, _stream()), "toad_gated_pool_fwd_f32")
     return a_raw, m, stats
 
 
@@ -146,10 +186,11 @@ def gated_pool_bwd(p, d: int, h, wc, a_raw, stats, m, dm, da_ext=None, dwc=None,
     _chk(dp, "dp"); _chk(dh, "dh"); _chk(dwc, "dwc"); _chk(dbc, "dbc")
     lib = _lib.load()
     ws = _ws(lib.toad_gated_pool_bwd_ws_bytes(n, l, d, t), p.device)
-    _lib.check(lib.toad_gated_pool_bwd_f32(_p(p), p.data_ptr() + 4 * d, ldp, _p(h), _p(wc), _p(a_raw), _p(stats), _p(m),
-                                           _p(dm), _p(da_ext), _p(dp), dp.data_ptr() + 4 * d, ldp, _p(dh), _p(dwc),
-                                           _p(dbc), float(beta), _p(ws), ws.numel(), n, l, d, t, _stream()),
-               "toad_gated_pool_bwd_f32")
+    with _timed("pool_bwd"):
+        _lib.check(lib.toad_gated_pool_bwd_f32(_p(p), p.data_ptr() + 4 * d, ldp, _p(h), _p(wc), _p(a_raw), _p(stats), _p(m),
+                                               _p(dm), _p(da_ext), _p(dp), dp.data_ptr() + 4 * d, ldp, _p(dh), _p(dwc),
+                                               _p(dbc), float(beta), _p(ws), ws.numel(), n, l, d, t, _stream()),
+                   "toad_gated_pool_bwd_f32")
     return dp, dh, dwc, dbc
 
 
