@@ -43,21 +43,58 @@ def pool_fwd_bytes(n):                     # 5,128 B/patch + c
     return 4 * (n * (2 * D + L + T) + T * D + T + T * L)
 
 
-def cpu_baseline(n_patches: int, budget_s: float = 25.0):
-    """fwd + loss + bwd of the CPU oracle on all host cores; bounded sample (>=1 warm-up + >=2 reps)."""
+def _physical_cores() -> int:
+    try:
+        pairs = set()
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(n_patches: int, budget_s: float = 30.0):
+    """fwd + loss + bwd of the CPU oracle on the host cores; bounded sample.
+    PyTorch-CPU does not scale to every hardware thread of a big host (256 threads on this pool's
+    boxes run ~7x slower than 64), so a few thread counts are probed with one repetition each and
+    the FASTEST is then timed (median of >=3) — the baseline is the best the CPU path can do here."""
     from oracle import toad_oracle as orc       # checker / reported baseline only
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    logical = os.cpu_count() or 1
+    phys = min(_physical_cores(), logical)
     params = orc.xavier_params(C, seed=1)
     x = torch.randn(n_patches, L0, generator=torch.Generator().manual_seed(1000))
     sex = torch.tensor([0.0]); label = torch.tensor([0]); site = torch.tensor([0])
-    orc.fwd_bwd(params, x, sex, label, site)    # warm-up
-    times = []
-    t_start = time.perf_counter()
-    while len(times) < 2 or (time.perf_counter() - t_start < budget_s and len(times) < 10):
+
+    def once():
         t0 = time.perf_counter()
         orc.fwd_bwd(params, x, sex, label, site)
-        times.append(time.perf_counter() - t0)
+        return time.perf_counter() - t0
+
+    cands = sorted({max(1, phys // 4), max(1, phys // 2), phys}) if phys > 8 else [phys]
+    probe = {}
+    t_start = time.perf_counter()
+    for th in cands:
+        torch.set_num_threads(th)
+        once()                                   # warm-up at this thread count
+        probe[th] = once()
+        if time.perf_counter() - t_start > budget_s * 0.6:
+            break
+    best = min(probe, key=probe.get)
+    torch.set_num_threads(best)
+    times = [probe[best]]
+    while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 7):
+        times.append(once())
     times.sort()
     med = times[len(times) // 2]
     cpu_name = "unknown"
@@ -68,9 +105,11 @@ def cpu_baseline(n_patches: int, budget_s: float = 25.0):
                     cpu_name = line.split(":", 1)[1].strip(); break
     except OSError:
         pass
-    return {"value": round(1.0 / med, 4), "unit": "slides/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} x fwd+loss+bwd of one {n_patches}-patch x 1024-d bag after 1 warm-up, median; "
-                      f"oracle/toad_oracle.py (torch CPU, fp32) on {cpu_name}",
+    return {"value": round(1.0 / med, 4), "unit": "slides/s", "cores": best, "kind": "port",
+            "sample": f"median of {len(times)} x (fwd + weighted CE + bwd) of one {n_patches}-patch x 1024-d bag, "
+                      f"oracle/toad_oracle.py (torch CPU fp32, the reference's op sequence) on {cpu_name}, "
+                      f"{phys} physical / {logical} logical cores; threads probed {{"
+                      + ", ".join(f"{k}: {v * 1e3:.0f} ms" for k, v in probe.items()) + "}",
             "ms_per_slide": round(med * 1e3, 2)}
 
 
