@@ -70,10 +70,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(
     }
     f32x4 ra[4], rb[4];
     auto gload = [&](int k0) {
+#ifdef TOAD_ABLATE_NO_GLOAD      // tools/ubench only: measure the loop without its global loads
+        if (k0 > 0) return;
+#endif
         const bool kok = (k0 + c4 * 4) < K;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             ra[j] = (aok[j] && kok) ? ld4(ap[j] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef TOAD_ABLATE_NO_GLOAD_B
+            if (k0 > 0) continue;
+#endif
             rb[j] = (bok[j] && kok) ? ld4(bp[j] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -94,53 +100,105 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // Fragment pipeline: the four 8-deep k-groups of a tile are read one group ahead of the MFMAs
+    // that consume them, and the tile barrier sits BEFORE the last group's MFMAs, so the first
+    // fragments of the next tile are fetched under 16 MFMAs (1024 issue cycles) as well. A wave
+    // therefore never waits on LDS latency with an empty matrix pipe; it parks only for barrier skew.
+    struct Frag { f32x4 a0, a1, b0, b1; };
+    const int frag_off_a = (wm * 64 + li) * NT_LD + hi * 4;
+    const int frag_off_b = NT_TILE + (wn * 64 + li) * NT_LD + hi * 4;
+    auto fread = [&](int buf, int q) {
+        const float *base = smem + buf * 2 * NT_TILE;
+        Frag f;
+#ifdef TOAD_ABLATE_NO_FREAD
+        if (q >= 0) { asm volatile("" : "=v"(f.a0), "=v"(f.a1), "=v"(f.b0), "=v"(f.b1)); return f; }
+#endif
+        f.a0 = ld4(base + frag_off_a + q * 8);
+        f.a1 = ld4(base + frag_off_a + 32 * NT_LD + q * 8);
+        f.b0 = ld4(base + frag_off_b + q * 8);
+        f.b1 = ld4(base + frag_off_b + 32 * NT_LD + q * 8);
+        return f;
+    };
+    auto mma16 = [&](const Frag &f) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[s], f.b0[s], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[s], f.b1[s], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[s], f.b0[s], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[s], f.b1[s], acc[1][1], 0, 0, 0);
+        }
+    };
+
     const int nk = (K + BK - 1) / BK;
     gload(0);
     lstore(0);
     __syncthreads();
+    Frag f0 = fread(0, 0);
     for (int t = 0; t < nk; ++t) {
         const bool more = (t + 1) < nk;
+        const int buf = t & 1;
         if (more) gload((t + 1) * BK);
-        const float *As = smem + (t & 1) * 2 * NT_TILE, *Bs = As + NT_TILE;
-        const float *arow = As + (wm * 64 + li) * NT_LD + hi * 4;
-        const float *brow = Bs + (wn * 64 + li) * NT_LD + hi * 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 fa[2], fb[2];
-            fa[0] = ld4(arow + q * 8);
-            fa[1] = ld4(arow + 32 * NT_LD + q * 8);
-            fb[0] = ld4(brow + q * 8);
-            fb[1] = ld4(brow + 32 * NT_LD + q * 8);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
-        }
-        if (more) lstore((t + 1) & 1);
+        // sched_barrier(0) pins "issue the next group's ds_reads, THEN this group's 16 MFMAs":
+        // left alone, hipcc sinks the reads to just before their first use to save 16 VGPRs.
+        Frag f1 = fread(buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        Frag f2 = fread(buf, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        Frag f3 = fread(buf, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(f2);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef TOAD_ABLATE_NO_LSTORE
+        if (more) lstore(buf ^ 1);
+#endif
+#ifndef TOAD_ABLATE_NO_BARRIER
         __syncthreads();
+#endif
+        if (more) f0 = fread(buf ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(f3);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
-    // epilogue: acc reg r of lane (li,hi) is row (r&3)+8*(r>>2)+4*hi, column li of the 32x32 tile
+    // epilogue: acc reg r of lane (li,hi) is row (r&3)+8*(r>>2)+4*hi, column li of the 32x32 tile.
+    // Rows are clamped (not branched) for the addend/mask loads so all 16 loads of a sub-tile are
+    // issued back to back; only the stores are predicated.
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int col = n0 + wn * 64 + b * 32 + li;
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
+        const bool cok = col < N;
+        const int colc = cok ? col : N - 1;
+        const float bv = bias ? bias[colc] : 0.f;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
+            const int rbase = m0 + wm * 64 + a * 32 + 4 * hi;
+            float add[16], msk[16];
+            if (addend) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), M - 1);
+                    add[r] = addend[(int64_t)row * ldc + colc];
+                }
+            }
+            if (mask_src) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), M - 1);
+                    msk[r] = mask_src[(int64_t)row * ldc + colc];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (row >= M) continue;
-                const int64_t off = (int64_t)row * ldc + col;
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
                 float v = acc[a][b][r] + bv;
-                if (addend) v += addend[off];
+                if (addend) v += add[r];
                 if (relu) v = v > 0.f ? v : 0.f;
-                if (mask_src) v = mask_src[off] > 0.f ? v : 0.f;
-                C[off] = v;
+                if (mask_src) v = msk[r] > 0.f ? v : 0.f;
+                if (cok && row < M) C[(int64_t)row * ldc + col] = v;
             }
         }
     }
@@ -202,35 +260,70 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(
     float bsum = 0.f;
     const bool do_colsum = (colsum_slab != nullptr) && (tj == 0) && (tid < BM);
 
+    // operand fragments: lane (li,hi) reads floats (2li, 2li+1) of row 2s+hi -> sub-tiles 0/1.
+    // Same fragment pipeline as the NT kernel: 4 groups of 4 k-steps, read one group ahead,
+    // barrier before the last group's MFMAs.
+    struct Frag { f32x2 a[4], b[4]; };
+    const int frag_off_a = hi * TN_LD + wm * 64 + 2 * li;
+    const int frag_off_b = TN_TILE + hi * TN_LD + wn * 64 + 2 * li;
+    auto fread = [&](int buf, int q) {
+        const float *base = smem + buf * 2 * TN_TILE;
+        Frag f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f.a[s] = *reinterpret_cast<const f32x2 *>(base + frag_off_a + 2 * (4 * q + s) * TN_LD);
+            f.b[s] = *reinterpret_cast<const f32x2 *>(base + frag_off_b + 2 * (4 * q + s) * TN_LD);
+        }
+        return f;
+    };
+    auto mma16 = [&](const Frag &f) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s][0], f.b[s][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s][0], f.b[s][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s][1], f.b[s][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s][1], f.b[s][1], acc[1][1], 0, 0, 0);
+        }
+    };
+    auto colsum = [&](int buf) {
+        if (do_colsum) {
+            const float *As = smem + buf * 2 * TN_TILE;
+#pragma unroll
+            for (int r = 0; r < BK; ++r) bsum += As[r * TN_LD + tid];
+        }
+    };
+
     const int nk = (mend - mbeg + BK - 1) / BK;
     if (nk > 0) {
         gload(mbeg);
         lstore(0);
     }
     __syncthreads();
+    Frag f0;
+    if (nk > 0) f0 = fread(0, 0);
     for (int t = 0; t < nk; ++t) {
         const bool more = (t + 1) < nk;
+        const int buf = t & 1;
         if (more) gload(mbeg + (t + 1) * BK);
-        const float *As = smem + (t & 1) * 2 * TN_TILE, *Bs = As + TN_TILE;
-        // operand fragments: lane (li,hi) reads floats (2li, 2li+1) of row 2s+hi -> sub-tiles 0/1
-        const float *acol = As + hi * TN_LD + wm * 64 + 2 * li;
-        const float *bcol = Bs + hi * TN_LD + wn * 64 + 2 * li;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const f32x2 fa = *reinterpret_cast<const f32x2 *>(acol + 2 * s * TN_LD);
-            const f32x2 fb = *reinterpret_cast<const f32x2 *>(bcol + 2 * s * TN_LD);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
-        }
-        if (do_colsum) {
-#pragma unroll
-            for (int r = 0; r < BK; ++r) bsum += As[r * TN_LD + tid];
-        }
-        if (more) lstore((t + 1) & 1);
+        Frag f1 = fread(buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        Frag f2 = fread(buf, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        Frag f3 = fread(buf, 3);
+        colsum(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(f2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) lstore(buf ^ 1);
         __syncthreads();
+        if (more) f0 = fread(buf ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(f3);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // epilogue: sub-tile (a,b) element (ri, li) is output (i0+wm*64+2*ri+a, j0+wn*64+2*li+b)
@@ -299,17 +392,29 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
 }
 
 struct WgradPlan { int nsplit, rows_per_split, tiles_i, tiles_j; };
+// Split-M plan. All tiles of one split run on one XCD (split s -> XCD s % 8) so the dY / X panels of
+// that split are fetched once into that XCD's L2. For the CUs to finish together every XCD must get
+// the same number of blocks and that number must be a multiple of its 32 CUs:
+//   tiles * splits_per_xcd % 32 == 0, with >= 2 blocks per CU when the reduction is long enough.
 static WgradPlan wgrad_plan(int64_t M, int64_t N, int64_t K) {
     WgradPlan p;
     p.tiles_i = (int)((N + BM - 1) / BM);
     p.tiles_j = (int)((K + BN - 1) / BN);
     const int tiles = p.tiles_i * p.tiles_j;
-    // aim at ~2 blocks per CU (512 blocks), at least 8 reduction steps (256 rows) per split
-    int want = (512 + tiles - 1) / tiles;
-    int64_t maxs = (M + 255) / 256;
-    int ns = (int)(want < maxs ? want : maxs);
-    if (ns < 1) ns = 1;
-    int64_t rps = (M + ns - 1) / ns;
+    const int64_t max_splits = (M + 255) / 256;            // >= 8 reduction steps per split
+    int best = 1;
+    if (max_splits >= kNumXCD) {
+        int spx = 1;                                        // splits per XCD
+        while ((tiles * spx) % 32 != 0 && spx < 32) ++spx; // smallest balanced count
+        const int unit = spx;
+        while (tiles * spx < 64 && (int64_t)(spx + unit) * kNumXCD <= max_splits) spx += unit;   // >= 2 blocks / CU
+        if ((int64_t)spx * kNumXCD > max_splits) spx = (int)(max_splits / kNumXCD);
+        if (spx < 1) spx = 1;
+        best = spx * kNumXCD;
+    } else {
+        best = (int)max_splits;
+    }
+    int64_t rps = (M + best - 1) / best;
     rps = (rps + BK - 1) / BK * BK;
     p.rows_per_split = (int)rps;
     p.nsplit = (int)((M + rps - 1) / rps);
