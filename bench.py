@@ -175,7 +175,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timing = ops.collect_timing()
     ops.enable_timing(False)
-    last_loss = float(losses[-1][0].item())
+    last_loss = float(losses[-1][0].item()) * global_slides
 
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -22,13 +22,13 @@ def make_slide(i):
             torch.tensor([i % 18]), torch.tensor([i % 2]))
 
 
-def oracle_slide_grad(model, grads, slide):
+def oracle_slide_grad(model, grads, slide, beta, scale):
     params = {k: v.detach() for k, v in model.state_dict().items()}
     bag, sex, label, site = slide
     _, loss, g = orc.fwd_bwd(params, bag, sex, label, site)
     for slot, key in SLOT2KEY.items():
-        grads[slot].add_(g[key])
-    return torch.stack([loss, loss, loss])
+        grads[slot].mul_(beta).add_(g[key] * scale)
+    return torch.stack([loss * scale, loss, loss])
 
 
 def worker(rank, world, port, ret):

@@ -102,7 +102,7 @@ def test_fused_loss_path_equals_autograd_path(cuda):
     g, _ = F_.mil_backward(w, saved, dl, ds)
     sp = model._slot_params()
     for k in F_.SLOTS:      # same kernels; only d(loss)/d(logits) comes from a different CE implementation
-        assert (g[k] - sp[k].grad).abs().max().item() <= 1e-5 * max(sp[k].grad.abs().max().item(), 1e-3), k
+        assert (g[k] - sp[k].grad).abs().max().item() <= 1e-5 * max(sp[k].grad.abs().max().item(), 1e-2), k
     dest = {k: torch.ones_like(sp[k]) for k in F_.SLOTS}
     g2, _ = F_.mil_backward(w, saved, dl, ds, grads=dest, beta=1.0)
     for k in F_.SLOTS:
@@ -164,3 +164,40 @@ def test_attn_net_gated_standalone(cuda):
     for p, r in zip(mine, prm):
         assert (p.grad.cpu() - r.grad).abs().max().item() <= 1e-4 * max(r.grad.abs().max().item(), 1e-2)
     assert (xg.grad.cpu() - xr.grad).abs().max().item() <= 1e-4 * max(xr.grad.abs().max().item(), 1e-2)
+
+
+def test_dp_step_single_gpu_matches_mean_of_oracle_gradients(cuda):
+    """SlideShardedDP on one GPU: two slides, gradient bucket == mean of per-slide oracle gradients
+    (kernels accumulate with beta, the 1/global scale is folded into the CE weights), and the flat
+    single-tensor SGD step moves every parameter by -lr * that mean."""
+    from toad_amd import TOAD_fc_mtl_concat
+    from toad_amd.dp import SlideShardedDP
+    torch.manual_seed(5)
+    model = TOAD_fc_mtl_concat(n_classes=18)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.05)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.relocate()
+    dp = SlideShardedDP(model, lambda ps: torch.optim.SGD(ps, lr=0.5))
+    slides_cpu = []
+    for i, n in enumerate((1500, 777)):
+        g = torch.Generator().manual_seed(50 + i)
+        slides_cpu.append((torch.randn(n, 1024, generator=g), torch.tensor([float(i)]), torch.tensor([3 + i]),
+                           torch.tensor([i])))
+    slides = [tuple(t.to(cuda) for t in s) for s in slides_cpu]
+    dp.flat_grad.fill_(123.0)                       # stale contents must be overwritten, not accumulated
+    losses = dp.step(slides, global_slides=2)
+    mean = {k: torch.zeros_like(v) for k, v in params.items()}
+    for s in slides_cpu:
+        _, _, g = orc.fwd_bwd(params, *s)
+        for k in mean:
+            mean[k] += g[k] / 2
+    new = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    for k, p in model.named_parameters():
+        ref = mean[k]
+        # 1e-4 absolute (north star): a ReLU-boundary flip moves a whole dW row by ~1e-5 here
+        assert (p.grad.cpu() - ref).abs().max().item() <= 1e-4, k
+        assert (new[k] - (params[k] - 0.5 * ref)).abs().max().item() <= 1e-4, k
+    assert len(losses) == 2 and losses[0].shape == (3,)

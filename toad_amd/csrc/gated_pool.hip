@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace toad {
 
@@ -207,20 +208,22 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
 }
 
 // Merge G block partials: M[t,:] = sum_b exp(m_b - m) acc_b / l ; stats[t] = (m, l).
-// grid = (T*L/16) blocks; block = 256 threads = 4 float4 columns x 64 partial slices.
+// grid = T*L/8 blocks; block = 256 threads = 2 float4 columns x 128 partial slices. Every block
+// recomputes the (tiny) global max / sum of its task; exp2(-inf) = 0 makes empty partials vanish
+// without a branch.
 __global__ __launch_bounds__(256) void gated_pool_combine_kernel(const float *__restrict__ partials, int G, int L,
                                                                   int T, float *__restrict__ M,
                                                                   float *__restrict__ stats) {
     __shared__ float red[256];
-    __shared__ __attribute__((aligned(16))) float sacc[64][16];
+    __shared__ __attribute__((aligned(16))) float sacc[128][8];
     const int tid = threadIdx.x;
     const int64_t rec = pool_partial_floats(L, T);
-    const int blocks_per_t = L / 16;
-    const int t = blockIdx.x / blocks_per_t, col0 = (blockIdx.x % blocks_per_t) * 16;
+    const int blocks_per_t = L / 8;
+    const int t = blockIdx.x / blocks_per_t, col0 = (blockIdx.x % blocks_per_t) * 8;
+    const float *ml = partials + T * L + 2 * t;
 
-    // global max and sum for task t
     float mx = -INFINITY;
-    for (int b = tid; b < G; b += 256) mx = __builtin_fmaxf(mx, partials[b * rec + T * L + 2 * t]);
+    for (int b = tid; b < G; b += 256) mx = __builtin_fmaxf(mx, ml[b * rec]);
     red[tid] = mx;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -230,10 +233,7 @@ __global__ __launch_bounds__(256) void gated_pool_combine_kernel(const float *__
     mx = red[0];
     __syncthreads();
     float ls = 0.f;
-    for (int b = tid; b < G; b += 256) {
-        const float mb = partials[b * rec + T * L + 2 * t];
-        if (mb != -INFINITY) ls += partials[b * rec + T * L + 2 * t + 1] * fast_exp(mb - mx);
-    }
+    for (int b = tid; b < G; b += 256) ls += ml[b * rec + 1] * fast_exp(ml[b * rec] - mx);
     red[tid] = ls;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -242,18 +242,16 @@ __global__ __launch_bounds__(256) void gated_pool_combine_kernel(const float *__
     }
     ls = red[0];
 
-    const int q = tid & 3, slice = tid >> 2;
+    const int q = tid & 1, slice = tid >> 1;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int b = slice; b < G; b += 64) {
-        const float mb = partials[b * rec + T * L + 2 * t];
-        if (mb != -INFINITY) a += fast_exp(mb - mx) * ld4(partials + b * rec + t * L + col0 + q * 4);
-    }
+    for (int b = slice; b < G; b += 128)
+        a += fast_exp(ml[b * rec] - mx) * ld4(partials + b * rec + t * L + col0 + q * 4);
     st4(&sacc[slice][q * 4], a);
     __syncthreads();
-    if (tid < 16) {
+    if (tid < 8) {
         float v = 0.f;
 #pragma unroll 8
-        for (int s = 0; s < 64; ++s) v += sacc[s][tid];
+        for (int s = 0; s < 128; ++s) v += sacc[s][tid];
         M[t * L + col0 + tid] = v / ls;
     }
     if (blockIdx.x % blocks_per_t == 0 && tid == 0) {
@@ -424,20 +422,23 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
     if (tid < T) out[T * D + tid] = s_db[0][tid] + s_db[1][tid] + s_db[2][tid] + s_db[3][tid];
 }
 
-// out[e] = beta*out[e] + sum_b partials[b][e]; e < n (two destinations: dWc [T*D] then dbc [T])
+// out[e] = beta*out[e] + sum_b partials[b][e]; e < n (two destinations: dWc [T*D] then dbc [T]).
+// block = 4 outputs x 64 partial slices, fixed summation order.
 __global__ __launch_bounds__(256) void bwd_partial_reduce_kernel(const float *__restrict__ partials, int G, int64_t rec,
                                                                   int n_w, int n_b, float *dWc, float *dbc,
                                                                   float beta) {
-    __shared__ float red[4][64];
-    const int tid = threadIdx.x, colq = tid & 63, slice = tid >> 6;
-    const int e = blockIdx.x * 64 + colq;
+    __shared__ float red[64][4];
+    const int tid = threadIdx.x, o = tid & 3, slice = tid >> 2;
+    const int e = blockIdx.x * 4 + o;
     float v = 0.f;
     if (e < n_w + n_b)
-        for (int b = slice; b < G; b += 4) v += partials[b * rec + e];
-    red[slice][colq] = v;
+        for (int b = slice; b < G; b += 64) v += partials[b * rec + e];
+    red[slice][o] = v;
     __syncthreads();
-    if (slice == 0 && e < n_w + n_b) {
-        v = red[0][colq] + red[1][colq] + red[2][colq] + red[3][colq];
+    if (tid < 4 && e < n_w + n_b) {
+        v = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) v += red[k][tid];
         float *dst = e < n_w ? dWc + e : dbc + (e - n_w);
         *dst = (beta != 0.f ? beta * *dst : 0.f) + v;
     }
@@ -448,7 +449,12 @@ __global__ __launch_bounds__(256) void bwd_partial_reduce_kernel(const float *__
 // ------------------------------------------------------------------------------------------
 static int pool_grid(int64_t N) {
     const int64_t ntiles = (N + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP;
-    const int64_t cap = 256 * 3;   // 3 resident blocks per CU (VGPR-limited), block-cyclic tiles
+    static int64_t cap = 0;        // blocks: a small multiple of the 256 CUs, block-cyclic 16-row tiles
+    if (cap == 0) {
+        const char *e = getenv("TOAD_POOL_GRID");      // tuning knob (tools/kernel_bench.py sweeps it)
+        cap = e ? atoll(e) : 256 * 3;
+        if (cap < 1) cap = 256 * 3;
+    }
     return (int)(ntiles < cap ? ntiles : cap);
 }
 
@@ -528,7 +534,7 @@ extern "C" int toad_gated_pool_fwd_f32(const float *Pa, const float *Pb, int64_t
     launch_fwd<true>(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, bc, A_raw, (float *)ws, (int)N);
     int rc = check_launch(what);
     if (rc) return rc;
-    hipLaunchKernelGGL(gated_pool_combine_kernel, dim3(T * L / 16), dim3(256), 0, st, (const float *)ws, grid, L, T, M, stats);
+    hipLaunchKernelGGL(gated_pool_combine_kernel, dim3(T * L / 8), dim3(256), 0, st, (const float *)ws, grid, L, T, M, stats);
     return check_launch(what);
 }
 
@@ -555,7 +561,7 @@ extern "C" int toad_gated_pool_bwd_f32(const float *Pa, const float *Pb, int64_t
     int rc = check_launch(what);
     if (rc) return rc;
     const int n = T * D + T;
-    hipLaunchKernelGGL(bwd_partial_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float *)ws, grid,
+    hipLaunchKernelGGL(bwd_partial_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, st, (const float *)ws, grid,
                        bwd_partial_floats(D, T), T * D, T, dWc, dbc, beta);
     return check_launch(what);
 }

@@ -344,15 +344,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(
     if (do_colsum && (i0 + tid) < I) colsum_slab[(int64_t)split * I + i0 + tid] = bsum;
 }
 
-// out[e] = beta*out[e] + sum_s slab[s][e]   (fixed order -> run-to-run deterministic)
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab, float *out,
-                                                           int64_t n, int nsplit, float beta) {
-    const int64_t n4 = n >> 2;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
-        f32x4 s = ld4(slab + e * 4);
-        for (int k = 1; k < nsplit; ++k) s += ld4(slab + (int64_t)k * n + e * 4);
-        if (beta != 0.f) s += beta * ld4(out + e * 4);
-        st4(out + e * 4, s);
+// out[e] = beta*out[e] + sum_s slab[s][e]   (fixed order -> run-to-run deterministic).
+// One launch reduces the weight slabs (n floats each) and, behind them, the bias slabs (n2 each).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab, float *out, int64_t n,
+                                                           const float *__restrict__ slab2, float *out2, int64_t n2,
+                                                           int nsplit, float beta) {
+    const int64_t n4 = n >> 2, m4 = n2 >> 2;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4 + m4; e += (int64_t)gridDim.x * blockDim.x) {
+        const bool second = e >= n4;
+        const float *src = second ? slab2 + (e - n4) * 4 : slab + e * 4;
+        float *dst = second ? out2 + (e - n4) * 4 : out + e * 4;
+        const int64_t stride = second ? n2 : n;
+        f32x4 s = ld4(src);
+        for (int k = 1; k < nsplit; ++k) s += ld4(src + (int64_t)k * stride);
+        if (beta != 0.f) s += beta * ld4(dst);
+        st4(dst, s);
     }
 }
 
@@ -471,17 +477,11 @@ extern "C" int toad_linear_wgrad_f32(const float *dY, const float *X, float *dW,
                        (int)K, p.rows_per_split, p.tiles_i, p.tiles_j, p.nsplit);
     int rc = check_launch(what);
     if (rc) return rc;
-    const int64_t n = N * K;
-    int rgrid = (int)((n / 4 + 255) / 256);
-    if (rgrid > 2048) rgrid = 2048;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, st, slab, dW, n, p.nsplit, beta);
-    rc = check_launch(what);
-    if (rc) return rc;
-    if (db) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)((N / 4 + 255) / 256)), dim3(256), 0, st, cs, db, N, p.nsplit, beta);
-        rc = check_launch(what);
-    }
-    return rc;
+    const int64_t n = N * K, n2 = db ? N : 0;
+    int rgrid = (int)(((n + n2) / 4 + 255) / 256);
+    if (rgrid > 4096) rgrid = 4096;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, st, slab, dW, n, cs, db, n2, p.nsplit, beta);
+    return check_launch(what);
 }
 
 extern "C" int toad_transpose_f32(const float *in, float *out, int64_t rows, int64_t cols, void *stream) {

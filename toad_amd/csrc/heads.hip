@@ -37,7 +37,7 @@ __device__ void wave_softmax_argmax(const float *lg, int n, float *prob, int64_t
     if (lane == 0) *hat = best == INT32_MAX ? 0 : best;
 }
 
-__global__ __launch_bounds__(256) void heads_fwd_kernel(const float *__restrict__ M, const float *__restrict__ sex,
+__global__ __launch_bounds__(1024) void heads_fwd_kernel(const float *__restrict__ M, const float *__restrict__ sex,
                                                          const float *__restrict__ Wcls, const float *__restrict__ bcls,
                                                          const float *__restrict__ Wsite, const float *__restrict__ bsite,
                                                          float *Mcat, float *logits, float *Y_prob, int64_t *Y_hat,
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float *__restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int LP = L + 1;
     const float sx = sex[0];
-    for (int e = tid; e < 2 * LP; e += 256) {
+    for (int e = tid; e < 2 * LP; e += 1024) {
         const int t = e / LP, k = e % LP;
         const float v = k < L ? M[t * L + k] : sx;
         s_m[e] = v;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float *__restrict_
     }
     __syncthreads();
     // rows 0..C-1: classifier on Mcat[0]; rows C, C+1: site classifier on Mcat[1]
-    for (int r = wave; r < C + 2; r += 4) {
+    for (int r = wave; r < C + 2; r += 16) {
         const float *w = r < C ? Wcls + (int64_t)r * LP : Wsite + (int64_t)(r - C) * LP;
         const float *x = r < C ? s_m : s_m + LP;
         float p = 0.f;
@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float *__restrict_
     if (wave == 1) wave_softmax_argmax(site_logits, 2, site_prob, site_hat, lane);
 }
 
+// grid.y = C + 2 weight rows (classifier rows then the two site rows) + 1 extra row for dM;
+// grid.x covers the L+1 columns. Every element is independent.
 __global__ __launch_bounds__(256) void heads_bwd_kernel(const float *__restrict__ Mcat, const float *__restrict__ dlogits,
                                                          const float *__restrict__ dsite, const float *__restrict__ Wcls,
                                                          const float *__restrict__ Wsite, const float *__restrict__ dMcat_ext,
@@ -78,27 +80,23 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float *__restrict_
                                                          float *dM, float beta, int L, int C) {
     const int LP = L + 1;
     const int k = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
     if (k >= LP) return;
-    const float x0 = Mcat[k], x1 = Mcat[LP + k];
-    float d0 = 0.f, d1 = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float g = dlogits[c];
-        const int64_t o = (int64_t)c * LP + k;
-        dWcls[o] = (beta != 0.f ? beta * dWcls[o] : 0.f) + g * x0;
-        d0 = fmaf(g, Wcls[o], d0);
-    }
-    for (int c = 0; c < 2; ++c) {
-        const float g = dsite[c];
-        const int o = c * LP + k;
-        dWsite[o] = (beta != 0.f ? beta * dWsite[o] : 0.f) + g * x1;
-        d1 = fmaf(g, Wsite[o], d1);
-    }
-    if (k < L) {
+    if (r < C) {
+        const int64_t o = (int64_t)r * LP + k;
+        dWcls[o] = (beta != 0.f ? beta * dWcls[o] : 0.f) + dlogits[r] * Mcat[k];
+        if (k == 0) dbcls[r] = (beta != 0.f ? beta * dbcls[r] : 0.f) + dlogits[r];
+    } else if (r < C + 2) {
+        const int c = r - C, o = c * LP + k;
+        dWsite[o] = (beta != 0.f ? beta * dWsite[o] : 0.f) + dsite[c] * Mcat[LP + k];
+        if (k == 0) dbsite[c] = (beta != 0.f ? beta * dbsite[c] : 0.f) + dsite[c];
+    } else if (k < L) {
+        float d0 = 0.f;
+        for (int c = 0; c < C; ++c) d0 = fmaf(dlogits[c], Wcls[(int64_t)c * LP + k], d0);
+        const float d1 = fmaf(dsite[1], Wsite[LP + k], dsite[0] * Wsite[k]);
         dM[k] = d0 + (dMcat_ext ? dMcat_ext[k] : 0.f);
         dM[L + k] = d1 + (dMcat_ext ? dMcat_ext[LP + k] : 0.f);
     }
-    if (k < C) dbcls[k] = (beta != 0.f ? beta * dbcls[k] : 0.f) + dlogits[k];
-    if (k < 2) dbsite[k] = (beta != 0.f ? beta * dbsite[k] : 0.f) + dsite[k];
 }
 
 // one wave: loss and d loss / d logits for w_cls*CE(logits,label) + w_site*CE(site_logits,site)
@@ -136,7 +134,7 @@ extern "C" int toad_heads_fwd_f32(const float *M, const float *sex, const float 
     const char *what = "toad_heads_fwd_f32";
     if (!M || !sex || !Wcls || !bcls || !Wsite || !bsite || !Mcat || !logits || !Y_prob || !Y_hat || !site_logits || !site_prob || !site_hat) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (L <= 0 || L > 8192 || C <= 0 || C > 1024) { set_error("%s: unsupported L=%d C=%d", what, L, C); return TOAD_ESHAPE; }
-    hipLaunchKernelGGL(heads_fwd_kernel, dim3(1), dim3(256), 2 * (L + 1) * sizeof(float), (hipStream_t)stream, M, sex, Wcls,
+    hipLaunchKernelGGL(heads_fwd_kernel, dim3(1), dim3(1024), 2 * (L + 1) * sizeof(float), (hipStream_t)stream, M, sex, Wcls,
                        bcls, Wsite, bsite, Mcat, logits, Y_prob, Y_hat, site_logits, site_prob, site_hat, L, C);
     return check_launch(what);
 }
@@ -147,7 +145,7 @@ extern "C" int toad_heads_bwd_f32(const float *Mcat, const float *dlogits, const
     const char *what = "toad_heads_bwd_f32";
     if (!Mcat || !dlogits || !dsite || !Wcls || !Wsite || !dWcls || !dbcls || !dWsite || !dbsite || !dM) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (L <= 0 || L > 8192 || C <= 0 || C > 1024 || C > L) { set_error("%s: unsupported L=%d C=%d", what, L, C); return TOAD_ESHAPE; }
-    hipLaunchKernelGGL(heads_bwd_kernel, dim3((L + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, Mcat, dlogits, dsite,
+    hipLaunchKernelGGL(heads_bwd_kernel, dim3((L + 1 + 255) / 256, C + 3), dim3(256), 0, (hipStream_t)stream, Mcat, dlogits, dsite,
                        Wcls, Wsite, dMcat_ext, dWcls, dbcls, dWsite, dbsite, dM, beta, L, C);
     return check_launch(what);
 }

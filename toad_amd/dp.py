@@ -41,15 +41,18 @@ def shard_by_length(lengths: Sequence[int], rank: int, world: int) -> List[int]:
     return sorted(mine)
 
 
-def hip_slide_grad(model, grads: Dict[str, torch.Tensor], slide: Slide, w_cls: float = 0.75, w_site: float = 0.25):
+def hip_slide_grad(model, grads: Dict[str, torch.Tensor], slide: Slide, beta: float = 1.0, scale: float = 1.0,
+                   w_cls: float = 0.75, w_site: float = 0.25):
     """forward + weighted CE (utils/core_utils_mtl_concat.py:213-215) + backward for one slide on the
-    HIP kernels, accumulating into ``grads`` (beta = 1). Returns the device loss vector [3]."""
+    HIP kernels: grads = beta*grads + scale * d(loss)/d(params). ``scale`` (1/global_slides) is folded
+    into the CE weights, so no separate gradient-scaling kernel runs. Returns the device loss vector
+    [3] = (scale*loss, cls CE, site CE)."""
     from . import functional as F_, ops
     bag, sex, label, site = slide
     w = {k: v.detach() for k, v in model._weights().items()}
     outs, saved = F_.mil_forward(w, bag, sex.to(torch.float32).reshape(1))
-    loss, dl, ds = ops.mtl_ce_fwd_bwd(outs["logits"], outs["site_logits"], label, site, w_cls, w_site)
-    F_.mil_backward(w, saved, dl, ds, grads=grads, beta=1.0)
+    loss, dl, ds = ops.mtl_ce_fwd_bwd(outs["logits"], outs["site_logits"], label, site, w_cls * scale, w_site * scale)
+    F_.mil_backward(w, saved, dl, ds, grads=grads, beta=beta)
     return loss
 
 
@@ -70,32 +73,41 @@ class SlideShardedDP:
         for k, p in sp.items():
             o, n = offs[k]
             v = self.flat_grad[o:o + n].view_as(p)
-            p.grad = v                          # the optimiser reads the bucket in place
+            p.grad = v                          # per-parameter views of the bucket (inspection / hooks)
             self.grads[k] = v
         d, l = sp["wa"].shape
         oa, ob = offs["wa"][0], offs["ba"][0]
         self.grads["wab"] = self.flat_grad[oa:oa + 2 * d * l].view(2 * d, l)   # stacked [dWa;dWb]
         self.grads["bab"] = self.flat_grad[ob:ob + 2 * d]
-        self.optimizer = optimizer_factory(list(model.parameters()))
+        # the optimiser sees ONE tensor (the flat buffer; alignment padding has zero gradient and stays
+        # zero), so the update is a single elementwise launch instead of a 14-tensor multi-tensor apply
+        self.flat_param = torch.nn.Parameter(self.flat, requires_grad=True)
+        self.flat_param.grad = self.flat_grad
+        self.optimizer = optimizer_factory([self.flat_param])
         self.slide_grad_fn = slide_grad_fn or hip_slide_grad
 
     def zero_grad(self):
         self.flat_grad.zero_()
 
-    def accumulate(self, slides: Sequence[Slide]):
-        losses = [self.slide_grad_fn(self.model, self.grads, s) for s in slides]
-        return losses
+    def accumulate(self, slides: Sequence[Slide], global_slides: int, overwrite: bool = True):
+        """grads (+)= sum over ``slides`` of d(loss)/d(params) / global_slides. With ``overwrite`` the
+        first slide is written with beta = 0, which replaces a zeroing pass over the bucket."""
+        if not slides:
+            if overwrite:
+                self.zero_grad()
+            return []
+        scale = 1.0 / float(global_slides)
+        return [self.slide_grad_fn(self.model, self.grads, s, 0.0 if (overwrite and i == 0) else 1.0, scale)
+                for i, s in enumerate(slides)]
 
-    def reduce(self, global_slides: int):
+    def reduce(self):
         if self.world > 1:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-        self.flat_grad.mul_(1.0 / float(global_slides))
 
     def step(self, slides: Sequence[Slide], global_slides: int):
         """One optimiser step over a global batch of ``global_slides`` slides, of which ``slides``
         are this rank's share. Returns the per-slide device loss vectors (no host sync)."""
-        self.zero_grad()
-        losses = self.accumulate(slides)
-        self.reduce(global_slides)
+        losses = self.accumulate(slides, global_slides)
+        self.reduce()
         self.optimizer.step()
         return losses
