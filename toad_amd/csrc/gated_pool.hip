@@ -25,8 +25,38 @@
 namespace toad {
 
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr int POOL_THREADS = 256;          // 4 waves
-constexpr int ROWS_PER_BLOCK_STEP = 16;    // 4 waves x 4 rows
+#ifndef TOAD_POOL_WAVES
+#define TOAD_POOL_WAVES 4
+#endif
+constexpr int NW = TOAD_POOL_WAVES;        // waves per block
+constexpr int POOL_THREADS = 64 * NW;
+constexpr int LPR = 32;                    // lanes per patch row (a wave streams 64/LPR rows per step)
+constexpr int RPW = 64 / LPR;              // rows per wave step
+constexpr int ROWS_PER_BLOCK_STEP = NW * RPW;
+
+// all-reduce over the LPR lanes that share a row (DPP inside 16-lane rows, one cross-row exchange)
+__device__ __forceinline__ float row_allreduce_sum(float v) {
+    v = row16_allreduce_sum(v);
+    if (LPR == 32) v += __shfl_xor(v, 16);
+    return v;
+}
+// sum over the RPW row-groups of a wave: lanes c, c+LPR, ... hold the same columns
+__device__ __forceinline__ float groups_sum(float v) {
+    if (LPR == 16) v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// streamed-once operands (P, H rows) use non-temporal loads: measured in the training step
+// (bench.py, N=100k) the fused forward drops 105.6 -> 80.7 us and the backward 182 -> 167 us;
+// -DTOAD_POOL_PLAIN_LOADS rebuilds the plain-load arm for A/B runs.
+__device__ __forceinline__ f32x4 ld4s(const float *p) {
+#ifdef TOAD_POOL_PLAIN_LOADS
+    return ld4(p);
+#else
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+#endif
+}
 
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
 
@@ -54,23 +84,23 @@ __host__ __device__ inline int64_t pool_partial_floats(int L, int T) { return (i
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int T, int DQ /* = D/64 float4 per lane */, int LQ /* = L/64 float4 per lane */, bool POOL>
+template <int T, int DQ /* = D/(4*LPR) float4 per lane */, int LQ /* = L/(4*LPR) float4 per lane */, bool POOL>
 __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
     const float *__restrict__ Pa, const float *__restrict__ Pb, int64_t ldp, const float *__restrict__ H,
     const float *__restrict__ Wc, const float *__restrict__ bc, float *__restrict__ A_raw,
     float *__restrict__ partials, int N) {
-    constexpr int D = DQ * 64, L = LQ * 64;
+    constexpr int D = DQ * 4 * LPR, L = LQ * 4 * LPR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = lane >> 4, c = lane & 15;       // 16-lane group = one row; c = float4 slot
+    const int grp = lane / LPR, c = lane % LPR;     // LPR-lane group = one row; c = float4 slot
 
-    // Wc columns owned by this lane: float4 index c + 16 j
+    // Wc columns owned by this lane: float4 index c + LPR j
     f32x4 wc[T][DQ];
     float bcv[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         bcv[t] = bc[t];
 #pragma unroll
-        for (int j = 0; j < DQ; ++j) wc[t][j] = ld4(Wc + t * D + (c + 16 * j) * 4);
+        for (int j = 0; j < DQ; ++j) wc[t][j] = ld4(Wc + t * D + (c + LPR * j) * 4);
     }
 
     float m[T], l[T];
@@ -85,7 +115,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
 
     const int ntiles = (N + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int row = tile * ROWS_PER_BLOCK_STEP + wave * 4 + grp;
+        const int row = tile * ROWS_PER_BLOCK_STEP + wave * RPW + grp;
         const bool valid = row < N;
         const int64_t rr = valid ? row : 0;
         const float *pa = Pa + rr * ldp + c * 4;
@@ -93,14 +123,14 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
         f32x4 xa[DQ], xb[DQ];
 #pragma unroll
         for (int j = 0; j < DQ; ++j) {
-            xa[j] = ld4(pa + 64 * j);
-            xb[j] = ld4(pb + 64 * j);
+            xa[j] = ld4s(pa + 4 * LPR * j);
+            xb[j] = ld4s(pb + 4 * LPR * j);
         }
         f32x4 hv[POOL ? LQ : 1];
         if (POOL) {
             const float *hp = H + rr * L + c * 4;
 #pragma unroll
-            for (int j = 0; j < LQ; ++j) hv[j] = ld4(hp + 64 * j);
+            for (int j = 0; j < LQ; ++j) hv[j] = ld4s(hp + 4 * LPR * j);
         }
 
         float s[T];
@@ -116,7 +146,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
             }
         }
 #pragma unroll
-        for (int t = 0; t < T; ++t) s[t] = row16_allreduce_sum(s[t]) + bcv[t];
+        for (int t = 0; t < T; ++t) s[t] = row_allreduce_sum(s[t]) + bcv[t];
 
         if (valid && c == 0) {
             if (T == 2) {
@@ -158,36 +188,28 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
     if (!POOL) return;
 
     // ---- merge the 16 (group, wave) partials of this block -------------------------------
-    __shared__ float sm_m[16][T];
-    __shared__ __attribute__((aligned(16))) float sm_acc[4][T][L];
-    __shared__ float sm_l[4][T];
+    __shared__ float sm_m[NW * RPW][T];
+    __shared__ __attribute__((aligned(16))) float sm_acc[NW][T][L];
+    __shared__ float sm_l[NW][T];
     __shared__ float sm_mb[T];
     if (c == 0) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) sm_m[wave * 4 + grp][t] = m[t];
+        for (int t = 0; t < T; ++t) sm_m[wave * RPW + grp][t] = m[t];
     }
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         float mb = sm_m[0][t];
 #pragma unroll
-        for (int k = 1; k < 16; ++k) mb = __builtin_fmaxf(mb, sm_m[k][t]);
+        for (int k = 1; k < NW * RPW; ++k) mb = __builtin_fmaxf(mb, sm_m[k][t]);
         const float f = (m[t] == -INFINITY) ? 0.f : fast_exp(m[t] - mb);
-        float lt = l[t] * f;
-        // sum the 4 groups of the wave: lanes c, c+16, c+32, c+48 hold the same columns
-        lt += __shfl_xor(lt, 16);
-        lt += __shfl_xor(lt, 32);
+        float lt = groups_sum(l[t] * f);      // every lane of a row group carries the same l
 #pragma unroll
         for (int j = 0; j < LQ; ++j) {
             f32x4 v = acc[t][j] * f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = v[e];
-                x += __shfl_xor(x, 16);
-                x += __shfl_xor(x, 32);
-                v[e] = x;
-            }
-            if (grp == 0) st4(&sm_acc[wave][t][(c + 16 * j) * 4], v);
+            for (int e = 0; e < 4; ++e) v[e] = groups_sum(v[e]);
+            if (grp == 0) st4(&sm_acc[wave][t][(c + LPR * j) * 4], v);
         }
         if (lane == 0) sm_l[wave][t] = lt;
         if (tid == 0) sm_mb[t] = mb;   // block max (same value in every thread)
@@ -198,12 +220,15 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
         const int t = e / (L / 4), q = e % (L / 4);
         f32x4 v = ld4(&sm_acc[0][t][q * 4]);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) v += ld4(&sm_acc[w][t][q * 4]);
+        for (int w = 1; w < NW; ++w) v += ld4(&sm_acc[w][t][q * 4]);
         st4(out + t * L + q * 4, v);
     }
     if (tid < T) {
+        float lsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) lsum += sm_l[w][tid];
         out[T * L + 2 * tid] = sm_mb[tid];
-        out[T * L + 2 * tid + 1] = sm_l[0][tid] + sm_l[1][tid] + sm_l[2][tid] + sm_l[3][tid];
+        out[T * L + 2 * tid + 1] = lsum;
     }
 }
 
@@ -273,14 +298,14 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
     const float *__restrict__ Mp, const float *__restrict__ dM, const float *__restrict__ dA_ext,
     float *__restrict__ dPa, float *__restrict__ dPb, int64_t ldd, float *__restrict__ dH,
     float *__restrict__ partials, int N) {
-    constexpr int D = DQ * 64, L = LQ * 64;
+    constexpr int D = DQ * 4 * LPR, L = LQ * 4 * LPR;
     __shared__ __attribute__((aligned(16))) float s_dm[T][L];
     __shared__ __attribute__((aligned(16))) float s_wc[T][D];
-    __shared__ __attribute__((aligned(16))) float s_red[4][T][D];
+    __shared__ __attribute__((aligned(16))) float s_red[NW][T][D];
     __shared__ float s_c[T];
-    __shared__ float s_db[4][T];
+    __shared__ float s_db[NW][T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = lane >> 4, c = lane & 15;
+    const int grp = lane / LPR, c = lane % LPR;
 
     for (int e = tid; e < T * L; e += POOL_THREADS) s_dm[e / L][e % L] = dM[e];
     for (int e = tid; e < T * D; e += POOL_THREADS) s_wc[e / D][e % D] = Wc[e];
@@ -312,21 +337,21 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
 
     const int ntiles = (N + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int row = tile * ROWS_PER_BLOCK_STEP + wave * 4 + grp;
+        const int row = tile * ROWS_PER_BLOCK_STEP + wave * RPW + grp;
         const bool valid = row < N;
         const int64_t rr = valid ? row : 0;
         // issue every load of the step up front
         const float *hp = H + rr * L + c * 4;
         f32x4 hv[LQ];
 #pragma unroll
-        for (int j = 0; j < LQ; ++j) hv[j] = ld4(hp + 64 * j);
+        for (int j = 0; j < LQ; ++j) hv[j] = ld4s(hp + 4 * LPR * j);
         const float *pa = Pa + rr * ldp + c * 4;
         const float *pb = Pb + rr * ldp + c * 4;
         f32x4 xa[DQ], xb[DQ];
 #pragma unroll
         for (int j = 0; j < DQ; ++j) {
-            xa[j] = ld4(pa + 64 * j);
-            xb[j] = ld4(pb + 64 * j);
+            xa[j] = ld4s(pa + 4 * LPR * j);
+            xb[j] = ld4s(pb + 4 * LPR * j);
         }
         float p[T], ds[T];
 #pragma unroll
@@ -346,16 +371,16 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                const f32x4 d = ld4(&s_dm[t][(c + 16 * j) * 4]);
+                const f32x4 d = ld4(&s_dm[t][(c + LPR * j) * 4]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dot[t] = fmaf(d[e], hv[j][e], dot[t]);
                 o += p[t] * d;
             }
-            if (valid) st4(dhp + 64 * j, o);
+            if (valid) st4(dhp + 4 * LPR * j, o);
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            dot[t] = row16_allreduce_sum(dot[t]);
+            dot[t] = row_allreduce_sum(dot[t]);
             ds[t] += p[t] * (dot[t] - ct[t]);
             if (c == 0) dbc[t] += ds[t];
         }
@@ -368,7 +393,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
             f32x4 oa, ob;
             f32x4 w[T];
 #pragma unroll
-            for (int t = 0; t < T; ++t) w[t] = ld4(&s_wc[t][(c + 16 * j) * 4]);
+            for (int t = 0; t < T; ++t) w[t] = ld4(&s_wc[t][(c + LPR * j) * 4]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float a, b;
@@ -384,8 +409,8 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
                 ob[e] = dg * g * (1.f - b);
             }
             if (valid) {
-                st4(dpa + 64 * j, oa);
-                st4(dpb + 64 * j, ob);
+                st4(dpa + 4 * LPR * j, oa);
+                st4(dpb + 4 * LPR * j, ob);
             }
         }
     }
@@ -393,21 +418,14 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
     // ---- block reduction of dWc / dbc partials (fixed order) ----------------------------
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        float b = dbc[t];   // non-zero only on c == 0 lanes
-        b += __shfl_xor(b, 16);
-        b += __shfl_xor(b, 32);
+        const float b = groups_sum(dbc[t]);   // non-zero only on c == 0 lanes
         if (lane == 0) s_db[wave][t] = b;
 #pragma unroll
         for (int j = 0; j < DQ; ++j) {
             f32x4 v = dwc[t][j];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = v[e];
-                x += __shfl_xor(x, 16);
-                x += __shfl_xor(x, 32);
-                v[e] = x;
-            }
-            if (grp == 0) st4(&s_red[wave][t][(c + 16 * j) * 4], v);
+            for (int e = 0; e < 4; ++e) v[e] = groups_sum(v[e]);
+            if (grp == 0) st4(&s_red[wave][t][(c + LPR * j) * 4], v);
         }
     }
     __syncthreads();
@@ -416,10 +434,15 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
         const int t = e / (D / 4), q = e % (D / 4);
         f32x4 v = ld4(&s_red[0][t][q * 4]);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) v += ld4(&s_red[w][t][q * 4]);
+        for (int w = 1; w < NW; ++w) v += ld4(&s_red[w][t][q * 4]);
         st4(out + t * D + q * 4, v);
     }
-    if (tid < T) out[T * D + tid] = s_db[0][tid] + s_db[1][tid] + s_db[2][tid] + s_db[3][tid];
+    if (tid < T) {
+        float bsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) bsum += s_db[w][tid];
+        out[T * D + tid] = bsum;
+    }
 }
 
 // out[e] = beta*out[e] + sum_b partials[b][e]; e < n (two destinations: dWc [T*D] then dbc [T]).
@@ -449,11 +472,12 @@ __global__ __launch_bounds__(256) void bwd_partial_reduce_kernel(const float *__
 // ------------------------------------------------------------------------------------------
 static int pool_grid(int64_t N) {
     const int64_t ntiles = (N + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP;
-    static int64_t cap = 0;        // blocks: a small multiple of the 256 CUs, block-cyclic 16-row tiles
+    static int64_t cap = 0;        // one 4-wave block per CU: the kernel runs at the per-CU load-path ceiling
+                                   // (~10 B/clk/CU) from one wave per SIMD; more blocks only add merge overhead
     if (cap == 0) {
         const char *e = getenv("TOAD_POOL_GRID");      // tuning knob (tools/kernel_bench.py sweeps it)
-        cap = e ? atoll(e) : 256 * 3;
-        if (cap < 1) cap = 256 * 3;
+        cap = e ? atoll(e) : 256;
+        if (cap < 1) cap = 256;
     }
     return (int)(ntiles < cap ? ntiles : cap);
 }
@@ -467,7 +491,7 @@ static void launch_fwd(int L, int D, int T, int grid, hipStream_t st, const floa
                        const float *H, const float *Wc, const float *bc, float *A_raw, float *partials, int N) {
 #define TOAD_FWD_CASE(TT, DD, LL)                                                                             \
     if (T == TT && D == DD && L == LL) {                                                                      \
-        hipLaunchKernelGGL((gated_pool_fwd_kernel<TT, DD / 64, LL / 64, POOL>), dim3(grid), dim3(POOL_THREADS), 0, st, \
+        hipLaunchKernelGGL((gated_pool_fwd_kernel<TT, DD / (4 * LPR), LL / (4 * LPR), POOL>), dim3(grid), dim3(POOL_THREADS), 0, st, \
                            Pa, Pb, ldp, H, Wc, bc, A_raw, partials, N);                                       \
         return;                                                                                               \
     }
@@ -488,7 +512,7 @@ static void launch_bwd(int L, int D, int T, int grid, hipStream_t st, const floa
                        float *partials, int N) {
 #define TOAD_BWD_CASE(TT, DD, LL)                                                                             \
     if (T == TT && D == DD && L == LL) {                                                                      \
-        hipLaunchKernelGGL((gated_pool_bwd_kernel<TT, DD / 64, LL / 64>), dim3(grid), dim3(POOL_THREADS), 0, st, Pa, \
+        hipLaunchKernelGGL((gated_pool_bwd_kernel<TT, DD / (4 * LPR), LL / (4 * LPR)>), dim3(grid), dim3(POOL_THREADS), 0, st, Pa, \
                            Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, partials, N);      \
         return;                                                                                               \
     }
