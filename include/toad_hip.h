@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOAD_ABI_VERSION 1
+#define TOAD_ABI_VERSION 2
 
 enum { TOAD_OK = 0, TOAD_EINVAL = -1, TOAD_ESHAPE = -2, TOAD_EWORKSPACE = -3, TOAD_EALIGN = -4 };
 enum { TOAD_ACT_NONE = 0, TOAD_ACT_RELU = 1 };
@@ -41,9 +41,13 @@ const char *toad_last_error(void);
 /* Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]).   bias may be NULL.
  * Replaces nn.Linear(+nn.ReLU): models/model_toad.py:59 and :62 (trunk, act=RELU) and the
  * attention_a / attention_b pre-activations :21,:25 (act=NONE, W = [Wa;Wb] stacked).
- * Requires K % 4 == 0. */
+ * Requires K % 4 == 0. `ws` (toad_linear_ws_bytes, also used by toad_linear_dgrad_f32) holds the
+ * fp32 slabs of K-split remainder tiles of the persistent 256x256 kernel; with ws == NULL, or
+ * K % 32 != 0, the generic 128x128 kernel runs instead. */
+size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K);
 int toad_linear_act_fwd_f32(const float *X, const float *W, const float *bias, float *Y,
-                            int64_t M, int64_t K, int64_t N, int act, void *stream);
+                            int64_t M, int64_t K, int64_t N, int act,
+                            void *ws, size_t ws_bytes, void *stream);
 
 /* dX[M,K] = (dY[M,N] W[N,K] + addend[M,K]) * (relu_src[M,K] > 0)
  * `WT` is W transposed, [K,N] row-major (see toad_transpose_f32).  addend and relu_src may be
@@ -53,7 +57,8 @@ int toad_linear_act_fwd_f32(const float *X, const float *W, const float *bias, f
  * Requires N % 4 == 0. */
 int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend,
                           const float *relu_src, float *dX,
-                          int64_t M, int64_t N, int64_t K, void *stream);
+                          int64_t M, int64_t N, int64_t K,
+                          void *ws, size_t ws_bytes, void *stream);
 
 /* dW[N,K] = beta*dW + dY[M,N]^T X[M,K];  db[N] = beta*db + column sums of dY (db may be NULL).
  * Split over M with a deterministic two-stage reduction through `ws`.

@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TOAD_HIP_LIB", os.path.join(_HERE, "libtoad_hip.so"))   # override: kernel A/B builds only
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 P, I64, I, F, SZ = c_void_p, c_int64, c_int, c_float, c_size_t
 
@@ -19,8 +19,9 @@ P, I64, I, F, SZ = c_void_p, c_int64, c_int, c_float, c_size_t
 SIGNATURES = {
     "toad_abi_version": (I, []),
     "toad_last_error": (c_char_p, []),
-    "toad_linear_act_fwd_f32": (I, [P, P, P, P, I64, I64, I64, I, P]),
-    "toad_linear_dgrad_f32": (I, [P, P, P, P, P, I64, I64, I64, P]),
+    "toad_linear_ws_bytes": (SZ, [I64, I64, I64]),
+    "toad_linear_act_fwd_f32": (I, [P, P, P, P, I64, I64, I64, I, P, SZ, P]),
+    "toad_linear_dgrad_f32": (I, [P, P, P, P, P, I64, I64, I64, P, SZ, P]),
     "toad_linear_wgrad_ws_bytes": (SZ, [I64, I64, I64]),
     "toad_linear_wgrad_f32": (I, [P, P, P, P, I64, I64, I64, F, P, SZ, P]),
     "toad_transpose_f32": (I, [P, P, I64, I64, P]),

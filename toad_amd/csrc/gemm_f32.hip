@@ -20,6 +20,9 @@
 // those reads conflict-free for the gfx950 ds_read_b128 lane groups.
 #include "common.h"
 
+#include <stdlib.h>
+#include <type_traits>
+
 namespace toad {
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -205,6 +208,281 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// NT, persistent 256x256 (the fast path; K % 32 == 0)
+//
+// Why this shape. Ablations (tools/ubench/gemm_ablate.cpp) showed the 128x128 kernels pay ~10 % for
+// operand staging even when the data is never waited for: a 128x128x32 step moves 32 KB per 1.05
+// MFLOP = 8 B/clk/CU at full MFMA rate, against a ~10-11 B/clk/CU vector-memory path. A 256x256
+// tile halves the bytes per FLOP (3.9 B/clk/CU) and needs 25 % fewer LDS fragment reads per MFMA.
+//
+//  * one persistent block of 8 waves per CU (grid = 256), waves 4(m) x 2(n), each 64x128 = 2x4
+//    MFMA 32x32 accumulators (128 acc VGPRs);
+//  * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B/lane): no staging VGPRs, no
+//    ds_write pass. LDS-DMA writes lane-linear, so the tile image is unpadded [256 pos][32 floats]
+//    and bank conflicts are removed by an XOR swizzle applied to the SOURCE address and to the
+//    fragment reads: 16-B chunk c of position p is stored at chunk c ^ ((p >> 1) & 7);
+//  * the B image is column-interleaved: position 32b+li of a wave's 128 columns holds column
+//    4li+b, so the four 32-wide MFMA sub-tiles of a lane are 4 CONSECUTIVE output columns and
+//    the epilogue moves 16 B per lane (bias/addend/mask loads and the store);
+//  * the k-loop runs across work items (the next item's first stage is in flight while the
+//    epilogue of the current one drains); fragments are read one k-group ahead and the stage
+//    barrier sits before the last group's MFMAs;
+//  * tile quantisation: every XCD plans its own tiles (row tiles x, x+8, ...; all column tiles of a
+//    row tile together). Full rounds are dealt to its 32 blocks; the REMAINDER tiles are split
+//    along K into g = 32/R pieces whose raw accumulators go to fp32 slabs, summed in fixed order
+//    (deterministic) by nt_fixup_kernel, which also applies the epilogue. Small bags (fewer tiles
+//    than CUs) are parallelised by the same mechanism.
+// ------------------------------------------------------------------------------------------
+constexpr int PB = 256;                                         // tile edge
+constexpr int PB_TILE = PB * BK;                                // floats per operand stage
+constexpr int PB_SMEM = 2 * 2 * PB_TILE * (int)sizeof(float);   // 131,072 B: one block per CU
+constexpr int PB_BLOCKS_PER_XCD = 32;
+constexpr int PB_GRID = kNumXCD * PB_BLOCKS_PER_XCD;
+constexpr int PB_GMAX = 16;                                     // max K-split of a remainder tile
+
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+struct NtPlan { int mt_x, tiles, rounds, rem, g; };
+__host__ __device__ inline NtPlan nt_plan(int xcd, int tiles_m, int tiles_n, int nk) {
+    NtPlan p;
+    p.mt_x = (tiles_m - xcd + kNumXCD - 1) / kNumXCD;
+    p.tiles = p.mt_x * tiles_n;
+    p.rounds = p.tiles / PB_BLOCKS_PER_XCD;
+    p.rem = p.tiles - p.rounds * PB_BLOCKS_PER_XCD;
+    int g = p.rem > 0 ? PB_BLOCKS_PER_XCD / p.rem : 0;
+    if (g > nk) g = nk;
+    if (g > PB_GMAX) g = PB_GMAX;
+    p.g = g;
+    return p;
+}
+
+// shared by the GEMM (direct tiles) and the fix-up kernel (slab sums): v = one float4 of 4 consecutive columns.
+// NOTE: bias/addend/mask are passed to the kernels as DIRECT pointer arguments. Inside a by-value struct
+// hipcc does not infer the global address space, emits FLAT loads, and a pending FLAT access makes it
+// put `s_waitcnt vmcnt(0) lgkmcnt(0)` in front of every LDS access that follows (found the hard way).
+__device__ __forceinline__ f32x4 apply_epilogue(f32x4 v, int relu, const float *add_p, const float *msk_p, f32x4 bv) {
+    v += bv;
+    if (add_p) v += ld4(add_p);
+    if (relu) { v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f; v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f; }
+    if (msk_p) {
+        const f32x4 m = ld4(msk_p);
+        v[0] = m[0] > 0.f ? v[0] : 0.f; v[1] = m[1] > 0.f ? v[1] : 0.f; v[2] = m[2] > 0.f ? v[2] : 0.f; v[3] = m[3] > 0.f ? v[3] : 0.f;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_f32_big_kernel(
+    const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
+    float *C, int64_t ldc, int M, int N, int K, const float *__restrict__ bias, int relu, const float *addend,
+    const float *__restrict__ mask_src, float *__restrict__ slabs, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, hi = lane >> 5;
+    const int nk = K / BK;
+
+    // ---- work list of this block
+    const int xcd = blockIdx.x % kNumXCD, j = blockIdx.x / kNumXCD;
+    const NtPlan pl = nt_plan(xcd, tiles_m, tiles_n, nk);
+    const bool has_part = j < pl.rem * pl.g;
+    const int n_items = pl.rounds + (has_part ? 1 : 0);
+    if (n_items == 0) return;
+    // item i < rounds: full tile q = j + i*32; item == rounds: k-slice `part` of remainder tile
+    const int part_tile = pl.g ? pl.rounds * PB_BLOCKS_PER_XCD + j / pl.g : 0;
+    const int part = pl.g ? j % pl.g : 0;
+    const int part_k0 = pl.g ? (part * nk) / pl.g : 0, part_k1 = pl.g ? ((part + 1) * nk) / pl.g : 0;
+    auto item_tile = [&](int i) { return i < pl.rounds ? j + i * PB_BLOCKS_PER_XCD : part_tile; };
+    auto item_k0 = [&](int i) { return i < pl.rounds ? 0 : part_k0; };
+    auto item_k1 = [&](int i) { return i < pl.rounds ? nk : part_k1; };
+    int total = pl.rounds * nk + (has_part ? part_k1 - part_k0 : 0);
+
+    // ---- staging. Wave w copies positions [32w, 32w+32) of the A image and of the B image, 8 per
+    //      instruction; lane l -> position 8jj + (l >> 3), physical chunk l & 7.
+    const char *Ab = reinterpret_cast<const char *>(A), *Bb = reinterpret_cast<const char *>(B);
+    unsigned aoff[4], boff[4];
+    auto set_tile = [&](int q, int &m0, int &n0) {
+        m0 = ((q / tiles_n) * kNumXCD + xcd) * PB;
+        n0 = (q % tiles_n) * PB;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int p = wave * 32 + 8 * jj + (lane >> 3);
+            const int ch = (lane & 7) ^ ((p >> 1) & 7);
+            const int pp = p & 127;
+            const int bcol = (p & 128) + 4 * (pp & 31) + (pp >> 5);         // column-interleaved B image
+            aoff[jj] = (unsigned)min(m0 + p, M - 1) * (unsigned)(lda * 4) + ch * 16;   // clamped rows are never stored
+            boff[jj] = (unsigned)min(n0 + bcol, N - 1) * (unsigned)(ldb * 4) + ch * 16;
+        }
+    };
+    // LDS-DMA is issued through inline asm: with the builtin, hipcc protects a possible alias between the
+    // DMA's LDS write and the following ds_reads with `s_waitcnt vmcnt(0)` right after the issue, which
+    // serialises load latency with the MFMAs. The asm form is invisible to that analysis; completion is
+    // enforced by hand with ONE `s_waitcnt vmcnt(0)` in front of the stage barrier (dma_wait). M0 (the LDS
+    // destination base) is compiler-reserved: saved, written and restored inside the same statement.
+    const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
+    auto dma1 = [&](const char *sbase, unsigned voff, unsigned lds_byte) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+    };
+    auto dma = [&](int buf, int kt) {
+        const unsigned dst = lds_base + (unsigned)(buf * 2 * PB_TILE + wave * 32 * BK) * 4u;
+        const char *ak = Ab + kt * (BK * 4), *bk = Bb + kt * (BK * 4);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            dma1(ak, aoff[jj], dst + jj * 8 * BK * 4);
+            dma1(bk, boff[jj], dst + (PB_TILE + jj * 8 * BK) * 4);
+        }
+    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+    // ---- fragments: lane (li,hi), k-group q reads logical chunk 2q+hi of its positions.
+    // Register budget (128 accumulators): B fragments are ROLLING - the 4 registers of sub-tile b are
+    // re-read for the next k-group right after the 8 MFMAs that consume them have issued (an MFMA
+    // reads its operands at issue) - and only the 8 A registers are double-buffered.
+    const int sw = (li >> 1) & 7;
+    const int apos = (wm * 64 + li) * BK, bpos = PB_TILE + (wn * 128 + li) * BK;
+    auto chunk = [&](int q) { return ((2 * q + hi) ^ sw) * 4; };
+    auto read_a = [&](int buf, int q, f32x4 (&fa)[2]) {
+        const float *base = smem + buf * 2 * PB_TILE + apos + chunk(q);
+        fa[0] = ld4(base);
+        fa[1] = ld4(base + 32 * BK);
+    };
+    auto read_b = [&](int buf, int q, int b) { return ld4(smem + buf * 2 * PB_TILE + bpos + b * 32 * BK + chunk(q)); };
+    f32x16 acc[2][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    };
+    f32x4 fa[2], fb[4];
+    // one k-group: 4 x (8 MFMAs on sub-tile column b, then refill fb[b] from (nbuf, nq)); A for the next
+    // group is fetched up front into na and swapped in at the end. `refill` = false on the very last group.
+    auto group = [&](int nbuf, int nq, bool refill) {
+        f32x4 na[2];
+        if (refill) read_a(nbuf, nq, na);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][s], fb[b][s], acc[0][b], 0, 0, 0);
+                acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][s], fb[b][s], acc[1][b], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (refill) fb[b] = read_b(nbuf, nq, b);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (refill) { fa[0] = na[0]; fa[1] = na[1]; }
+    };
+
+    // ---- epilogue. Lane (li,hi) holds, for sub-tile a and acc reg r, the 4 consecutive columns
+    //      n0 + wn*128 + 4li .. +3 of row m0 + wm*64 + a*32 + (r&3) + 8(r>>2) + 4hi.
+    // Addressing: row and column split into a wave-uniform part (SGPR base pointer per row) and ONE
+    // 32-bit per-lane element offset voff = 4*hi*ldc + 4*li that is the same for every row; otherwise
+    // LICM hoists 32 per-lane 64-bit row offsets out of the step loop (64 VGPRs -> spills).
+    auto epilogue = [&](int m0, int n0, bool partial) {
+        // opaque copies: everything derived below is then NOT loop-invariant for LICM, which would
+        // otherwise precompute ~60 per-lane values before the step loop and spill them
+        int li4 = 4 * li, hi4 = 4 * hi;
+        asm volatile("" : "+v"(li4), "+v"(hi4));
+        const int voff = hi4 * (int)ldc + li4;
+        const int svoff = hi4 * PB + li4;
+        const int ucol = n0 + wn * 128;
+        const bool cok = (ucol + li4) < N;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias && cok) bv = ld4(bias + ucol + li4);
+        // consume the load on EVERY path: a load destination that is still "pending" on some path at the
+        // back-edge makes hipcc guard the next step's ds_reads (same registers, WAW) with vmcnt(0), and
+        // that in-order wait also covers the freshly issued LDS-DMA of the next stage.
+        asm volatile("" : "+v"(bv));
+        float *slab = slabs + (int64_t)blockIdx.x * PB * PB + wn * 128;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int urow = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2);      // + 4*hi is in voff
+                f32x4 v = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+                if (partial) {
+                    st4(slab + urow * PB + svoff, v);
+                } else if (cok && (m0 + urow + hi4) < M) {
+                    const int64_t uoff = (int64_t)(m0 + urow) * ldc + ucol;            // wave-uniform
+                    st4(C + uoff + voff, apply_epilogue(v, relu, addend ? addend + uoff + voff : nullptr,
+                                                        mask_src ? mask_src + uoff + voff : nullptr, bv));
+                }
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most 4 rows of loads in flight: bounded registers
+            }
+        }
+    };
+
+    int it = 0, kt = item_k0(0), kend = item_k1(0);     // step being computed
+    int nit = 0, nkt = kt, nkend = kend;                // step being staged
+    int cur_m0, cur_n0, nxt_m0, nxt_n0;
+    set_tile(item_tile(0), cur_m0, cur_n0);
+    nxt_m0 = cur_m0; nxt_n0 = cur_n0;
+    dma(0, kt);
+    zero_acc();
+    dma_wait();
+    __syncthreads();
+    read_a(0, 0, fa);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) fb[b] = read_b(0, 0, b);
+    for (int step = 0; step < total; ++step) {
+        const int buf = step & 1;
+        const bool more = (step + 1) < total;
+        if (more) {                        // stage the next step (possibly the next item's first k-step)
+            if (++nkt == nkend) { ++nit; nkt = item_k0(nit); nkend = item_k1(nit); set_tile(item_tile(nit), nxt_m0, nxt_n0); }
+            dma(buf ^ 1, nkt);
+        }
+        group(buf, 1, true);
+        group(buf, 2, true);
+        group(buf, 3, true);
+        dma_wait();                        // this wave's share of the next stage has landed (also drains older stores) ...
+        __syncthreads();                   // ... everyone's has, and this stage is fully read
+        group(buf ^ 1, 0, more);           // last k-group from registers; refills come from the NEXT stage
+        if (++kt == kend) {                // item finished: stores are fire-and-forget, the next item's first
+            epilogue(cur_m0, cur_n0, it >= pl.rounds);     // stage is already in flight
+            zero_acc();
+            ++it;
+            kt = item_k0(it); kend = item_k1(it);
+            cur_m0 = nxt_m0; cur_n0 = nxt_n0;
+        }
+    }
+}
+
+// Remainder tiles: C tile = epilogue(sum of the g K-slice slabs), fixed order. grid = (16, 31, 8):
+// x = 16-row strip group of the tile, y = remainder tile index of the XCD, z = XCD.
+__global__ __launch_bounds__(256) void nt_fixup_kernel(const float *__restrict__ slabs, float *C, int64_t ldc, int M, int N,
+                                                        int K, const float *__restrict__ bias, int relu, const float *addend,
+                                                        const float *__restrict__ mask_src, int tiles_m, int tiles_n) {
+    const int xcd = blockIdx.z, tr = blockIdx.y;
+    const NtPlan pl = nt_plan(xcd, tiles_m, tiles_n, K / BK);
+    if (tr >= pl.rem || pl.g == 0) return;
+    const int q = pl.rounds * PB_BLOCKS_PER_XCD + tr;
+    const int m0 = ((q / tiles_n) * kNumXCD + xcd) * PB, n0 = (q % tiles_n) * PB;
+    const int c4 = threadIdx.x & 63, r0 = blockIdx.x * 16 + (threadIdx.x >> 6) * 4;
+    const int col = n0 + c4 * 4;
+    if (col >= N) return;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = ld4(bias + col);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int lrow = r0 + rr;
+        if (m0 + lrow >= M) continue;
+        // slab of K-slice p was written by block (xcd + 8*(tr*g + p))
+        f32x4 v = ld4(slabs + ((int64_t)(xcd + kNumXCD * (tr * pl.g)) * PB + lrow) * PB + c4 * 4);
+        for (int p = 1; p < pl.g; ++p)
+            v += ld4(slabs + ((int64_t)(xcd + kNumXCD * (tr * pl.g + p)) * PB + lrow) * PB + c4 * 4);
+        const int64_t off = (int64_t)(m0 + lrow) * ldc + col;
+        st4(C + off, apply_epilogue(v, relu, addend ? addend + off : nullptr, mask_src ? mask_src + off : nullptr, bv));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // TN (wgrad): slab[s][I,J] = sum_{m in split s} A[m,I] B[m,J];  colsum slab[s][I] = sum_m A[m,I]
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(
@@ -380,7 +658,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 // ------------------------------------------------------------------------------------------
 static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, const float *bias, int relu, const float *addend,
-                     const float *mask_src, hipStream_t st, const char *what) {
+                     const float *mask_src, void *ws, hipStream_t st, const char *what) {
     if (M <= 0 || N <= 0 || K <= 0) { set_error("%s: non-positive dimension", what); return TOAD_EINVAL; }
     if (M > INT32_MAX - BM || N > INT32_MAX - BN || K > INT32_MAX - BK) { set_error("%s: dimension too large", what); return TOAD_ESHAPE; }
     if (K % 4 != 0 || lda % 4 != 0 || ldb % 4 != 0) { set_error("%s: reduction dim %lld must be a multiple of 4", what, (long long)K); return TOAD_ESHAPE; }
@@ -390,6 +668,31 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
         hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_SMEM);
         attr_set = true;
     }
+    static int use_big = -1;
+    static float *slab_ws = nullptr;
+    if (use_big < 0) {
+        const char *e = getenv("TOAD_GEMM_BIG");           // A/B knob; default on
+        use_big = e ? atoi(e) : 1;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_f32_big_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM);
+    }
+    if (use_big && ws && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && (uint64_t)M * lda * 4 < (1ull << 32) &&
+        (uint64_t)N * ldb * 4 < (1ull << 32)) {
+        const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
+        hipLaunchKernelGGL(gemm_nt_f32_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, A, lda, B, ldb, C, ldc, (int)M,
+                           (int)N, (int)K, bias, relu, addend, mask_src, (float *)ws, tiles_m, tiles_n);
+        int rc = check_launch(what);
+        if (rc) return rc;
+        bool any_rem = false;
+        for (int x = 0; x < kNumXCD; ++x) any_rem |= nt_plan(x, tiles_m, tiles_n, (int)(K / BK)).rem > 0;
+        if (any_rem) {
+            hipLaunchKernelGGL(nt_fixup_kernel, dim3(16, PB_BLOCKS_PER_XCD - 1, kNumXCD), dim3(256), 0, st, (const float *)ws, C,
+                               ldc, (int)M, (int)N, (int)K, bias, relu, addend, mask_src, tiles_m, tiles_n);
+            rc = check_launch(what);
+        }
+        return rc;
+    }
+    (void)slab_ws;
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     const int grid = kNumXCD * ((tiles_m + kNumXCD - 1) / kNumXCD) * tiles_n;
     hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3(grid), dim3(256), NT_SMEM, st, A, lda, B, ldb, C, ldc, (int)M, (int)N,
@@ -431,20 +734,34 @@ static WgradPlan wgrad_plan(int64_t M, int64_t N, int64_t K) {
 
 using namespace toad;
 
+extern "C" size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K) {
+    (void)M; (void)N; (void)K;
+    return (size_t)PB_GRID * PB * PB * sizeof(float);     // one 256x256 fp32 slab per persistent block (64 MiB)
+}
+
+static int check_ws(void *ws, size_t ws_bytes, int64_t M, int64_t N, int64_t K, const char *what) {
+    if (ws && ws_bytes < toad_linear_ws_bytes(M, N, K)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
+    if (ws && !aligned16(ws)) { set_error("%s: workspace must be 16-byte aligned", what); return TOAD_EALIGN; }
+    return TOAD_OK;
+}
+
 extern "C" int toad_linear_act_fwd_f32(const float *X, const float *W, const float *bias, float *Y, int64_t M,
-                                        int64_t K, int64_t N, int act, void *stream) {
-    if (!X || !W || !Y) { set_error("toad_linear_act_fwd_f32: null pointer"); return TOAD_EINVAL; }
-    if (act != TOAD_ACT_NONE && act != TOAD_ACT_RELU) { set_error("toad_linear_act_fwd_f32: bad act %d", act); return TOAD_EINVAL; }
-    return launch_nt(X, K, W, K, Y, N, M, N, K, bias, act == TOAD_ACT_RELU, nullptr, nullptr, (hipStream_t)stream,
-                     "toad_linear_act_fwd_f32");
+                                        int64_t K, int64_t N, int act, void *ws, size_t ws_bytes, void *stream) {
+    const char *what = "toad_linear_act_fwd_f32";
+    if (!X || !W || !Y) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (act != TOAD_ACT_NONE && act != TOAD_ACT_RELU) { set_error("%s: bad act %d", what, act); return TOAD_EINVAL; }
+    if (int rc = check_ws(ws, ws_bytes, M, N, K, what)) return rc;
+    return launch_nt(X, K, W, K, Y, N, M, N, K, bias, act == TOAD_ACT_RELU, nullptr, nullptr, ws, (hipStream_t)stream, what);
 }
 
 extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend, const float *relu_src,
-                                      float *dX, int64_t M, int64_t N, int64_t K, void *stream) {
-    if (!dY || !WT || !dX) { set_error("toad_linear_dgrad_f32: null pointer"); return TOAD_EINVAL; }
+                                      float *dX, int64_t M, int64_t N, int64_t K, void *ws, size_t ws_bytes,
+                                      void *stream) {
+    const char *what = "toad_linear_dgrad_f32";
+    if (!dY || !WT || !dX) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (int rc = check_ws(ws, ws_bytes, M, K, N, what)) return rc;
     // dX[M,K] = dY[M,N] . WT[K,N]^T : an NT product with reduction dim N
-    return launch_nt(dY, N, WT, N, dX, K, M, K, N, nullptr, 0, addend, relu_src, (hipStream_t)stream,
-                     "toad_linear_dgrad_f32");
+    return launch_nt(dY, N, WT, N, dX, K, M, K, N, nullptr, 0, addend, relu_src, ws, (hipStream_t)stream, what);
 }
 
 extern "C" size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K) {

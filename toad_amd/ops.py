@@ -86,8 +86,10 @@ def linear_act_fwd(x, w, b, act: int, out: Optional[torch.Tensor] = None) -> tor
     y = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=x.device)
     _chk(y, "out")
     lib = _lib.load()
+    ws = _ws(lib.toad_linear_ws_bytes(m, n, k), x.device)
     with _timed("gemm_fwd"):
-        _lib.check(lib.toad_linear_act_fwd_f32(_p(x), _p(w), _p(b), _p(y), m, k, n, act, _stream()), "toad_linear_act_fwd_f32")
+        _lib.check(lib.toad_linear_act_fwd_f32(_p(x), _p(w), _p(b), _p(y), m, k, n, act, _p(ws), ws.numel(), _stream()),
+                   "toad_linear_act_fwd_f32")
     return y
 
 
@@ -111,9 +113,11 @@ def linear_dgrad(dy, wt, addend=None, relu_src=None, out: Optional[torch.Tensor]
     for t, nm in ((addend, "addend"), (relu_src, "relu_src"), (dx, "out")):
         if t is not None and tuple(t.shape) != (m, k):
             raise ValueError(f"linear_dgrad: {nm} must be [{m},{k}]")
+    lib = _lib.load()
+    ws = _ws(lib.toad_linear_ws_bytes(m, k, n), dy.device)
     with _timed("gemm_dgrad"):
-        _lib.check(_lib.load().toad_linear_dgrad_f32(_p(dy), _p(wt), _p(addend), _p(relu_src), _p(dx), m, n, k, _stream()),
-                   "toad_linear_dgrad_f32")
+        _lib.check(lib.toad_linear_dgrad_f32(_p(dy), _p(wt), _p(addend), _p(relu_src), _p(dx), m, n, k, _p(ws), ws.numel(),
+                                             _stream()), "toad_linear_dgrad_f32")
     return dx
 
 
