@@ -622,6 +622,213 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(
     if (do_colsum && (i0 + tid) < I) colsum_slab[(int64_t)split * I + i0 + tid] = bsum;
 }
 
+// ------------------------------------------------------------------------------------------
+// TN, persistent 256x256 (wgrad fast path): slab[s][I,J] = sum_{m in split s} A[m,I] B[m,J]
+//
+// Same machinery as gemm_nt_f32_big_kernel (one 8-wave block per CU, LDS-DMA stages issued through
+// inline asm, fragments read ahead, stage barrier before the last k-group, work items pipelined
+// across their boundaries). Differences:
+//  * the reduction runs over ROWS (patches): a stage is 32 rows x 256 columns of each operand, one
+//    1-KiB LDS-DMA per row, lane-linear -> the image needs no swizzle: A fragments are ds_read_b64
+//    (columns 2li,2li+1 -> sub-tiles a=0,1) and B fragments ds_read_b128 (columns 4li..4li+3 ->
+//    sub-tiles b=0..3, so the slab stores are 16 B), both conflict-free as laid out;
+//  * rows past the end of a split must contribute ZERO (they are reduction terms): the wave that
+//    staged such a row overwrites it with zeros after its own DMA has landed, before the barrier;
+//  * every item ends in a raw 256x256 slab (+ the column sums of A for the bias gradient when the
+//    item owns column tile 0); slab_reduce_kernel sums the splits in fixed order.
+// ------------------------------------------------------------------------------------------
+struct TnPlan { int ti, tj, tiles, spx, nsplit, rows_per_split; };
+static TnPlan tn_plan(int64_t M, int64_t I, int64_t J) {
+    TnPlan p;
+    p.ti = (int)((I + PB - 1) / PB);
+    p.tj = (int)((J + PB - 1) / PB);
+    p.tiles = p.ti * p.tj;
+    int spx = PB_BLOCKS_PER_XCD / p.tiles;                       // one item per block where possible
+    if (spx < 1) spx = 1;
+    const int64_t max_splits = (M + 127) / 128;                 // >= 4 stages per split
+    while (spx > 1 && (int64_t)spx * kNumXCD > max_splits) --spx;
+    int ns = spx * kNumXCD;
+    if (ns > max_splits) ns = (int)(max_splits < 1 ? 1 : max_splits);
+    int64_t rps = (M + ns - 1) / ns;
+    rps = (rps + BK - 1) / BK * BK;
+    p.rows_per_split = (int)rps;
+    p.nsplit = (int)((M + rps - 1) / rps);
+    p.spx = (p.nsplit + kNumXCD - 1) / kNumXCD;
+    return p;
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_f32_big_kernel(
+    const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
+    float *__restrict__ slab, float *__restrict__ colsum_slab, int Mred, int I, int J, int rows_per_split,
+    int ti, int tj, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int li = lane & 31, hi = lane >> 5;
+    const int tiles = ti * tj;
+
+    // ---- items of this block: XCD x owns splits x, x+8, ...; item idx -> (split_local, tile)
+    const int xcd = blockIdx.x % kNumXCD, jb = blockIdx.x / kNumXCD;
+    const int splits_x = (nsplit - xcd + kNumXCD - 1) / kNumXCD;
+    const int items_x = splits_x * tiles;
+    const int n_items = jb < items_x ? (items_x - jb + PB_BLOCKS_PER_XCD - 1) / PB_BLOCKS_PER_XCD : 0;
+    if (n_items == 0) return;
+    auto item_split = [&](int i) { return ((jb + i * PB_BLOCKS_PER_XCD) / tiles) * kNumXCD + xcd; };
+    auto item_tile = [&](int i) { return (jb + i * PB_BLOCKS_PER_XCD) % tiles; };
+    auto split_steps = [&](int sp) {
+        const int mb = sp * rows_per_split, me = min(Mred, mb + rows_per_split);
+        return (me - mb + BK - 1) / BK;
+    };
+    int total = 0;
+    for (int i = 0; i < n_items; ++i) total += split_steps(item_split(i));
+
+    // ---- staging: wave w copies rows 4w..4w+3 of both images (one 1-KiB DMA per row, lane l -> floats 4l..4l+3)
+    const char *Ab = reinterpret_cast<const char *>(A), *Bb = reinterpret_cast<const char *>(B);
+    const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
+    auto dma1 = [&](const char *sbase, unsigned voff, unsigned lds_byte) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+    };
+    unsigned avoff = 0, bvoff = 0;           // per-lane column byte offsets inside a row (clamped at the tile edge)
+    int st_i0 = 0, st_j0 = 0, st_mend = 0;   // tile / split end of the item being staged
+    auto set_item = [&](int i, int &mrow) {
+        const int sp = item_split(i), tl = item_tile(i);
+        st_i0 = (tl / tj) * PB; st_j0 = (tl % tj) * PB;
+        mrow = sp * rows_per_split;
+        st_mend = min(Mred, mrow + rows_per_split);
+        avoff = (unsigned)min(st_i0 + 4 * lane, I - 4) * 4u;
+        bvoff = (unsigned)min(st_j0 + 4 * lane, J - 4) * 4u;
+    };
+    // stage rows [m, m+32) of the staged item into buffer `buf`; returns how many of this wave's 4 rows are real
+    auto dma = [&](int buf, int m) {
+        const unsigned dst = lds_base + (unsigned)(buf * 2 * PB_TILE + wave * 4 * PB) * 4u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = min(m + wave * 4 + r, Mred - 1);               // clamped: valid address, zeroed later if past the split
+            dma1(Ab + (int64_t)row * (lda * 4), avoff, dst + r * PB * 4);
+            dma1(Bb + (int64_t)row * (ldb * 4), bvoff, dst + (PB_TILE + r * PB) * 4);
+        }
+    };
+    auto zero_tail = [&](int buf, int m, int mend) {                   // rare: only the last stage of a ragged split
+        if (m + 32 <= mend) return;
+        float *img = smem + buf * 2 * PB_TILE + wave * 4 * PB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (m + wave * 4 + r >= mend) {
+                st4(img + r * PB + 4 * lane, f32x4{0.f, 0.f, 0.f, 0.f});
+                st4(img + PB_TILE + r * PB + 4 * lane, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+        }
+    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+    // ---- fragments: k2-step s (0..15) uses image rows 2s+hi. 4-deep ring, refilled right after use.
+    const int aoffs = hi * PB + wi * 64 + 2 * li, boffs = PB_TILE + hi * PB + wj * 128 + 4 * li;
+    f32x2 fa[4];
+    f32x4 fb[4];
+    auto fread = [&](int buf, int s2, int slot) {
+        const float *base = smem + buf * 2 * PB_TILE + 2 * s2 * PB;
+        fa[slot] = *reinterpret_cast<const f32x2 *>(base + aoffs);
+        fb[slot] = ld4(base + boffs);
+    };
+    f32x16 acc[2][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    };
+    // one k-group = 4 k2-steps; after the 8 MFMAs of a step its ring slot is refilled from (nbuf, ns0 + step)
+    auto group = [&](int nbuf, int ns0, bool refill) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k][a], fb[k][b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (refill) fread(nbuf, ns0 + k, k);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    float bsum = 0.f;
+    auto colsum = [&](int buf, bool on) {     // column sums of the A image (bias gradient), threads 0..255
+        if (on && tid < PB) {
+            const float *As = smem + buf * 2 * PB_TILE;
+#pragma unroll 8
+            for (int r = 0; r < BK; ++r) bsum += As[r * PB + tid];
+        }
+    };
+    auto epilogue = [&](int sp, int i0, int j0, bool with_colsum) {
+        int li4 = 4 * li, hi4 = 4 * hi;
+        asm volatile("" : "+v"(li4), "+v"(hi4));                 // keep LICM from hoisting ~60 per-lane offsets
+        float *out = slab + (int64_t)sp * I * J;
+        const int col = j0 + wj * 128 + li4;
+        const bool cok = col < J;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wi * 64 + 2 * ((r & 3) + 8 * (r >> 2) + hi4) + a;
+                f32x4 v = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+                if (cok && row < I) st4(out + (int64_t)row * J + col, v);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (with_colsum && tid < PB && (i0 + tid) < I) colsum_slab[(int64_t)sp * I + i0 + tid] = bsum;
+        bsum = 0.f;
+    };
+
+    // ---- the step loop (flattened over items)
+    int it = 0, nit = 0;
+    int m_stage = 0;                          // first row of the stage being loaded
+    set_item(0, m_stage);
+    int cur_sp = item_split(0), cur_i0 = st_i0, cur_j0 = st_j0, cur_mend = st_mend;
+    int kt = 0, kend = split_steps(cur_sp);  // step being computed
+    int nkt = 0, nkend = kend;                // step being staged
+    bool cur_cs = colsum_slab != nullptr && cur_j0 == 0;
+    dma(0, m_stage);
+    zero_acc();
+    dma_wait();
+    zero_tail(0, m_stage, st_mend);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fread(0, k, k);
+    for (int step = 0; step < total; ++step) {
+        const int buf = step & 1;
+        const bool more = (step + 1) < total;
+        if (more) {
+            if (++nkt == nkend) { ++nit; nkt = 0; set_item(nit, m_stage); nkend = split_steps(item_split(nit)); }
+            else m_stage += BK;
+            dma(buf ^ 1, m_stage);
+        }
+        group(buf, 4, true);
+        group(buf, 8, true);
+        colsum(buf, cur_cs);
+        group(buf, 12, true);
+        dma_wait();
+        if (more) zero_tail(buf ^ 1, m_stage, st_mend);
+        __syncthreads();
+        group(buf ^ 1, 0, more);
+        if (++kt == kend) {
+            epilogue(cur_sp, cur_i0, cur_j0, cur_cs);
+            zero_acc();
+            ++it;
+            if (it < n_items) {
+                cur_sp = item_split(it); kt = 0; kend = split_steps(cur_sp);
+                cur_i0 = st_i0; cur_j0 = st_j0; cur_mend = st_mend;
+                cur_cs = colsum_slab != nullptr && cur_j0 == 0;
+            }
+        }
+    }
+    (void)cur_mend;
+}
+
 // out[e] = beta*out[e] + sum_s slab[s][e]   (fixed order -> run-to-run deterministic).
 // One launch reduces the weight slabs (n floats each) and, behind them, the bias slabs (n2 each).
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab, float *out, int64_t n,
@@ -764,10 +971,23 @@ extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const flo
     return launch_nt(dY, N, WT, N, dX, K, M, K, N, nullptr, 0, addend, relu_src, ws, (hipStream_t)stream, what);
 }
 
+static bool tn_big_ok(int64_t M, int64_t N, int64_t K) {
+    static int use_big = -1;
+    if (use_big < 0) {
+        const char *e = getenv("TOAD_GEMM_BIG");           // A/B knob; default on
+        use_big = e ? atoi(e) : 1;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f32_big_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM);
+    }
+    return use_big && M >= 128 && N >= 4 && K >= 4;
+}
+
 extern "C" size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const WgradPlan p = wgrad_plan(M, N, K);
-    return (size_t)p.nsplit * (size_t)(N * K + N) * sizeof(float);
+    const TnPlan q = tn_plan(M, N, K);
+    const int ns = p.nsplit > q.nsplit ? p.nsplit : q.nsplit;
+    return (size_t)ns * (size_t)(N * K + N) * sizeof(float);
 }
 
 extern "C" int toad_linear_wgrad_f32(const float *dY, const float *X, float *dW, float *db, int64_t M, int64_t N,
@@ -780,24 +1000,37 @@ extern "C" int toad_linear_wgrad_f32(const float *dY, const float *X, float *dW,
     if (!aligned16(dY) || !aligned16(X) || !aligned16(dW) || !aligned16(ws)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
     if (ws_bytes < toad_linear_wgrad_ws_bytes(M, N, K)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN_SMEM);
-        attr_set = true;
-    }
-    const WgradPlan p = wgrad_plan(M, N, K);
     float *slab = (float *)ws;
-    float *cs = db ? slab + (size_t)p.nsplit * N * K : nullptr;
-    const int tiles = p.tiles_i * p.tiles_j;
-    const int grid = kNumXCD * ((p.nsplit + kNumXCD - 1) / kNumXCD) * tiles;
-    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(grid), dim3(256), TN_SMEM, st, dY, N, X, K, slab, cs, (int)M, (int)N,
-                       (int)K, p.rows_per_split, p.tiles_i, p.tiles_j, p.nsplit);
-    int rc = check_launch(what);
+    int nsplit;
+    int rc;
+    if (tn_big_ok(M, N, K)) {
+        const TnPlan q = tn_plan(M, N, K);
+        nsplit = q.nsplit;
+        float *cs = db ? slab + (size_t)nsplit * N * K : nullptr;
+        hipLaunchKernelGGL(gemm_tn_f32_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, X, K, slab, cs, (int)M, (int)N,
+                           (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
+        rc = check_launch(what);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN_SMEM);
+            attr_set = true;
+        }
+        const WgradPlan p = wgrad_plan(M, N, K);
+        nsplit = p.nsplit;
+        float *cs = db ? slab + (size_t)nsplit * N * K : nullptr;
+        const int tiles = p.tiles_i * p.tiles_j;
+        const int grid = kNumXCD * ((p.nsplit + kNumXCD - 1) / kNumXCD) * tiles;
+        hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(grid), dim3(256), TN_SMEM, st, dY, N, X, K, slab, cs, (int)M, (int)N,
+                           (int)K, p.rows_per_split, p.tiles_i, p.tiles_j, p.nsplit);
+        rc = check_launch(what);
+    }
     if (rc) return rc;
+    float *cs = db ? slab + (size_t)nsplit * N * K : nullptr;
     const int64_t n = N * K, n2 = db ? N : 0;
     int rgrid = (int)(((n + n2) / 4 + 255) / 256);
     if (rgrid > 4096) rgrid = 4096;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, st, slab, dW, n, cs, db, n2, p.nsplit, beta);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, st, slab, dW, n, cs, db, n2, nsplit, beta);
     return check_launch(what);
 }
 
