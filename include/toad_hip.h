@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOAD_ABI_VERSION 2
+#define TOAD_ABI_VERSION 3
 
 enum { TOAD_OK = 0, TOAD_EINVAL = -1, TOAD_ESHAPE = -2, TOAD_EWORKSPACE = -3, TOAD_EALIGN = -4 };
 enum { TOAD_ACT_NONE = 0, TOAD_ACT_RELU = 1 };
@@ -41,22 +41,27 @@ const char *toad_last_error(void);
 /* Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]).   bias may be NULL.
  * Replaces nn.Linear(+nn.ReLU): models/model_toad.py:59 and :62 (trunk, act=RELU) and the
  * attention_a / attention_b pre-activations :21,:25 (act=NONE, W = [Wa;Wb] stacked).
+ * drop_p > 0 applies train-mode nn.Dropout(drop_p) after the activation (models/model_toad.py:61,64):
+ * element (row, col) is kept iff hash(drop_seed, row*N+col) >= drop_p*2^32 and then scaled by
+ * 1/(1-drop_p); the mask is never stored (toad_dropout_mask_f32 reproduces it).
  * Requires K % 4 == 0. `ws` (toad_linear_ws_bytes, also used by toad_linear_dgrad_f32) holds the
  * fp32 slabs of K-split remainder tiles of the persistent 256x256 kernel; with ws == NULL, or
  * K % 32 != 0, the generic 128x128 kernel runs instead. */
 size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K);
 int toad_linear_act_fwd_f32(const float *X, const float *W, const float *bias, float *Y,
                             int64_t M, int64_t K, int64_t N, int act,
+                            float drop_p, uint64_t drop_seed,
                             void *ws, size_t ws_bytes, void *stream);
 
-/* dX[M,K] = (dY[M,N] W[N,K] + addend[M,K]) * (relu_src[M,K] > 0)
- * `WT` is W transposed, [K,N] row-major (see toad_transpose_f32).  addend and relu_src may be
+/* dX[M,K] = (dY[M,N] W[N,K] + addend[M,K]) * (relu_src[M,K] > 0) * mask_scale
+ * mask_scale = 1, or 1/(1-p) when relu_src is a ReLU+Dropout(p) output (its zeros already encode the
+ * dropout mask).  `WT` is W transposed, [K,N] row-major (see toad_transpose_f32).  addend and relu_src may be
  * NULL (no add / no mask); dX may alias addend.
  * Replaces autograd's mm backward + threshold_backward behind loss.backward()
  * (utils/core_utils_mtl_concat.py:231) for models/model_toad.py:62 and :21,:25.
  * Requires N % 4 == 0. */
 int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend,
-                          const float *relu_src, float *dX,
+                          const float *relu_src, float mask_scale, float *dX,
                           int64_t M, int64_t N, int64_t K,
                           void *ws, size_t ws_bytes, void *stream);
 
@@ -69,6 +74,10 @@ size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K);
 int toad_linear_wgrad_f32(const float *dY, const float *X, float *dW, float *db,
                           int64_t M, int64_t N, int64_t K, float beta,
                           void *ws, size_t ws_bytes, void *stream);
+
+/* out[e] = the dropout multiplier (0 or 1/(1-p)) the kernels apply to flat element e under `drop_seed`
+ * (all ones when drop_p == 0). Lets a caller or test reproduce the masks, which are never stored. */
+int toad_dropout_mask_f32(float *out, int64_t n, float drop_p, uint64_t drop_seed, void *stream);
 
 /* out[cols,rows] = in[rows,cols]^T  (weight transposes for dgrad). */
 int toad_transpose_f32(const float *in, float *out, int64_t rows, int64_t cols, void *stream);
@@ -90,7 +99,10 @@ int toad_gated_pool_fwd_f32(const float *Pa, const float *Pb, int64_t ldp, const
                             const float *Wc, const float *bc,
                             float *A_raw, float *M, float *stats,
                             void *ws, size_t ws_bytes,
-                            int64_t N, int L, int D, int T, void *stream);
+                            int64_t N, int L, int D, int T,
+                            float drop_p, uint64_t seed_a, uint64_t seed_b, void *stream);
+/* drop_p > 0: train-mode Dropout(drop_p) on tanh(Pa) (stream seed_a) and on sigmoid(Pb) (seed_b),
+ * models/model_toad.py:27-29; element index = row*D + d. The backward takes the same seeds. */
 
 /* Backward of the above (autograd mirror, utils/core_utils_mtl_concat.py:231):
  *   p[i,t]  = exp(A_raw[i,t]-max_t)/sum_t
@@ -106,7 +118,8 @@ int toad_gated_pool_bwd_f32(const float *Pa, const float *Pb, int64_t ldp, const
                             float *dPa, float *dPb, int64_t ldd, float *dH,
                             float *dWc, float *dbc, float beta,
                             void *ws, size_t ws_bytes,
-                            int64_t N, int L, int D, int T, void *stream);
+                            int64_t N, int L, int D, int T,
+                            float drop_p, uint64_t seed_a, uint64_t seed_b, void *stream);
 
 /* ---- Classifier heads ---------------------------------------------------------------- */
 

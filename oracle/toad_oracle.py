@@ -105,9 +105,14 @@ def linear_act(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, act: str) -> t
     return y
 
 
-def gated_scores(pa: torch.Tensor, pb: torch.Tensor, wc: torch.Tensor, bc: torch.Tensor) -> torch.Tensor:
-    """Attn_Net_Gated.forward, models/model_toad.py:36-41: A = (tanh(pa) * sigmoid(pb)) Wc^T + bc -> [N,T]."""
-    g = torch.tanh(pa).mul(torch.sigmoid(pb))
+def gated_scores(pa: torch.Tensor, pb: torch.Tensor, wc: torch.Tensor, bc: torch.Tensor,
+                 ma: Optional[torch.Tensor] = None, mb: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Attn_Net_Gated.forward, models/model_toad.py:36-41: A = (tanh(pa) * sigmoid(pb)) Wc^T + bc -> [N,T].
+    ma/mb: train-mode Dropout(0.25) multipliers (0 or 1/(1-p)) after Tanh / Sigmoid (:27-29), or None."""
+    a, b = torch.tanh(pa), torch.sigmoid(pb)
+    if ma is not None:
+        a, b = a * ma, b * mb
+    g = a.mul(b)
     return torch.addmm(bc, g, wc.t())
 
 
@@ -117,9 +122,9 @@ def softmax_pool(a_raw_nt: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
     return torch.mm(a, h)
 
 
-def gated_pool_fwd(pa, pb, h, wc, bc):
+def gated_pool_fwd(pa, pb, h, wc, bc, ma=None, mb=None):
     """CPU twin of the fused HIP pool kernel: (A_raw[N,T], M[T,L])."""
-    a_raw = gated_scores(pa, pb, wc, bc)
+    a_raw = gated_scores(pa, pb, wc, bc, ma, mb)
     return a_raw, softmax_pool(a_raw, h)
 
 
@@ -145,20 +150,28 @@ class Saved:
     m: torch.Tensor          # [T, L] pooled (before the sex concat)
     mcat: torch.Tensor       # [T, L+1]
     sex: torch.Tensor
+    masks: Optional[Dict[str, torch.Tensor]] = None   # dropout multipliers {"h1","h","a","b"} (train + dropout=True)
 
 
 def forward(params: Dict[str, torch.Tensor], x: torch.Tensor, sex: torch.Tensor,
-            return_features: bool = False, attention_only: bool = False):
-    """TOAD_fc_mtl_concat.forward, models/model_toad.py:90-116 (dropout off / eval)."""
+            return_features: bool = False, attention_only: bool = False,
+            masks: Optional[Dict[str, torch.Tensor]] = None):
+    """TOAD_fc_mtl_concat.forward, models/model_toad.py:90-116. ``masks`` = explicit Dropout(0.25)
+    multipliers (0 or 4/3) for the four dropout sites (:61,:64,:27-29); None = dropout off / eval."""
     p = params
     h1 = linear_act(x, p["attention_net.0.weight"], p["attention_net.0.bias"], "relu")      # :59
+    if masks is not None:
+        h1 = h1 * masks["h1"]                                                                # :61
     h = linear_act(h1, p["attention_net.2.weight"], p["attention_net.2.bias"], "relu")      # :62
+    if masks is not None:
+        h = h * masks["h"]                                                                   # :64
     wab = torch.cat([p["attention_net.4.attention_a.0.weight"], p["attention_net.4.attention_b.0.weight"]], 0)
     bab = torch.cat([p["attention_net.4.attention_a.0.bias"], p["attention_net.4.attention_b.0.bias"]], 0)
     pre = linear_act(h, wab, bab, "none")                                                    # :21,:25
     d = wab.shape[0] // 2
     a_raw_nt = gated_scores(pre[:, :d], pre[:, d:], p["attention_net.4.attention_c.weight"],
-                            p["attention_net.4.attention_c.bias"])                           # :36-41
+                            p["attention_net.4.attention_c.bias"],
+                            None if masks is None else masks["a"], None if masks is None else masks["b"])   # :36-41
     a_tn = a_raw_nt.t()                                                                      # :92
     if attention_only:
         return a_tn[0]                                                                       # :93-94
@@ -171,7 +184,7 @@ def forward(params: Dict[str, torch.Tensor], x: torch.Tensor, sex: torch.Tensor,
         out["features"] = mcat                                                               # :110-111
     out.update({"logits": logits, "Y_prob": y_prob, "Y_hat": y_hat, "site_logits": site_logits,
                 "site_prob": site_prob, "site_hat": site_hat, "A": a_tn})                     # :113-114
-    saved = Saved(x=x, h1=h1, h=h, p=pre, a_raw=a_raw_nt, m=m, mcat=mcat, sex=sex)
+    saved = Saved(x=x, h1=h1, h=h, p=pre, a_raw=a_raw_nt, m=m, mcat=mcat, sex=sex, masks=masks)
     return out, saved
 
 
@@ -203,7 +216,7 @@ def heads_bwd(mcat, dlogits, dsite, wcls, wsite):
     return dwcls, dlogits[0].clone(), dwsite, dsite[0].clone(), dm
 
 
-def gated_pool_bwd(pa, pb, h, wc, a_raw, m, dm, da_ext: Optional[torch.Tensor] = None):
+def gated_pool_bwd(pa, pb, h, wc, a_raw, m, dm, da_ext: Optional[torch.Tensor] = None, ma=None, mb=None):
     """Backward of models/model_toad.py:36-41,92-98.
 
     dS[i,t] = p[i,t] * (dM[t].H[i] - dM[t].M[t]) (+ external dA_raw), p = softmax over i.
@@ -217,22 +230,27 @@ def gated_pool_bwd(pa, pb, h, wc, a_raw, m, dm, da_ext: Optional[torch.Tensor] =
     dh = p @ dm                                              # [N,L]
     a = torch.tanh(pa)
     b = torch.sigmoid(pb)
-    g = a * b
+    ka = 1.0 if ma is None else ma                           # dropout multipliers after tanh / sigmoid
+    kb = 1.0 if mb is None else mb
+    ad, bd = a * ka, b * kb
+    g = ad * bd
     dg = ds @ wc                                             # [N,D]
-    dpa = dg * b * (1.0 - a * a)
-    dpb = dg * a * b * (1.0 - b)
+    dpa = dg * bd * ka * (1.0 - a * a)
+    dpb = dg * ad * kb * b * (1.0 - b)
     dwc = ds.t() @ g
     dbc = ds.sum(dim=0)
     return dpa, dpb, dh, dwc, dbc
 
 
-def linear_bwd(x, w, y_act, dy, act: str, dx_add: Optional[torch.Tensor] = None, need_dx: bool = True):
-    """Backward of y = act(x W^T + b). ``dy`` is the grad wrt the *activated* output.
+def linear_bwd(x, w, y_act, dy, act: str, dx_add: Optional[torch.Tensor] = None, need_dx: bool = True,
+               mask_scale: float = 1.0):
+    """Backward of y = dropout(act(x W^T + b)). ``dy`` is the grad wrt the saved output y_act.
 
-    Returns (dx, dW, db).  For relu the mask is y_act > 0 (same as torch's threshold_backward).
+    Returns (dx, dW, db).  For relu the mask is y_act > 0 (same as torch's threshold_backward); with
+    dropout y_act's zeros already include the dropped elements and kept ones carry ``mask_scale`` = 1/(1-p).
     """
     if act == "relu":
-        dy = dy * (y_act > 0).to(dy.dtype)
+        dy = dy * (y_act > 0).to(dy.dtype) * mask_scale
     dw = dy.t() @ x
     db = dy.sum(dim=0)
     dx = dy @ w if need_dx else None
@@ -252,24 +270,27 @@ def backward(params: Dict[str, torch.Tensor], s: Saved, dlogits, dsite,
                                                  p["site_classifier.weight"])
     g["classifier.weight"], g["classifier.bias"] = dwcls, dbcls
     g["site_classifier.weight"], g["site_classifier.bias"] = dwsite, dbsite
+    mk = s.masks
+    msc = 1.0 if mk is None else 1.0 / 0.75
     dpa, dpb, dh_pool, dwc, dbc = gated_pool_bwd(s.p[:, :d], s.p[:, d:], s.h,
-                                                 p["attention_net.4.attention_c.weight"], s.a_raw, s.m, dm, da_ext)
+                                                 p["attention_net.4.attention_c.weight"], s.a_raw, s.m, dm, da_ext,
+                                                 None if mk is None else mk["a"], None if mk is None else mk["b"])
     g["attention_net.4.attention_c.weight"], g["attention_net.4.attention_c.bias"] = dwc, dbc
     dp = torch.cat([dpa, dpb], 1)
     # attention_a/b Linear: dH = dP Wab + dH_pool ; dWab = dP^T H
     dh, dwab, dbab = linear_bwd(s.h, wab, s.p, dp, "none", dx_add=dh_pool)
     g["attention_net.4.attention_a.0.weight"], g["attention_net.4.attention_b.0.weight"] = dwab[:d], dwab[d:]
     g["attention_net.4.attention_a.0.bias"], g["attention_net.4.attention_b.0.bias"] = dbab[:d], dbab[d:]
-    dh1, dw2, db2 = linear_bwd(s.h1, p["attention_net.2.weight"], s.h, dh, "relu")
+    dh1, dw2, db2 = linear_bwd(s.h1, p["attention_net.2.weight"], s.h, dh, "relu", mask_scale=msc)
     g["attention_net.2.weight"], g["attention_net.2.bias"] = dw2, db2
-    _, dw1, db1 = linear_bwd(s.x, p["attention_net.0.weight"], s.h1, dh1, "relu", need_dx=False)
+    _, dw1, db1 = linear_bwd(s.x, p["attention_net.0.weight"], s.h1, dh1, "relu", need_dx=False, mask_scale=msc)
     g["attention_net.0.weight"], g["attention_net.0.bias"] = dw1, db1
     return g
 
 
-def fwd_bwd(params, x, sex, label, site):
+def fwd_bwd(params, x, sex, label, site, masks=None):
     """One training-step's worth of math: forward, weighted CE, backward. Returns (out, loss, grads)."""
-    out, saved = forward(params, x, sex)
+    out, saved = forward(params, x, sex, masks=masks)
     loss = loss_fn(out["logits"], label, out["site_logits"], site)
     dlogits, dsite = loss_grad(out["logits"], label, out["site_logits"], site)
     grads = backward(params, saved, dlogits, dsite)

@@ -30,7 +30,7 @@ def test_library_exports_every_header_symbol():
 def test_argument_errors_are_reported_without_a_gpu():
     from toad_amd import _lib
     lib = _lib.load()
-    rc = lib.toad_linear_act_fwd_f32(None, None, None, None, 4, 4, 4, 0, None, 0, None)
+    rc = lib.toad_linear_act_fwd_f32(None, None, None, None, 4, 4, 4, 0, 0.0, 0, None, 0, None)
     assert rc == -1 and b"null pointer" in lib.toad_last_error()
     assert lib.toad_gated_pool_ws_bytes(1000, 512, 384, 2) > 0
     assert lib.toad_gated_pool_ws_bytes(1000, 500, 384, 2) == 0      # unsupported shape

@@ -54,7 +54,7 @@ def test_backward_chain_tight_with_identical_relu_masks(cuda, golden, name):
     saved_cpu = orc.Saved(x=ci["x"], h1=sv.h1.cpu(), h=sv.h.cpu(), p=sv.p.cpu(), a_raw=sv.a_raw.cpu(),
                           m=sv.m.cpu(), mcat=sv.mcat.cpu(), sex=ci["sex"])
     og = orc.backward({k: v.double() for k, v in ci["params"].items()},
-                      orc.Saved(**{k: (v.double() if v.is_floating_point() else v) for k, v in saved_cpu.__dict__.items()}),
+                      orc.Saved(**{k: (v.double() if (v is not None and v.is_floating_point()) else v) for k, v in saved_cpu.__dict__.items()}),
                       dl.double(), ds.double())
     for sl, k in SLOT2KEY.items():
         ref = og[k]
@@ -201,3 +201,81 @@ def test_dp_step_single_gpu_matches_mean_of_oracle_gradients(cuda):
         assert (p.grad.cpu() - ref).abs().max().item() <= 1e-4, k
         assert (new[k] - (params[k] - 0.5 * ref)).abs().max().item() <= 1e-4, k
     assert len(losses) == 2 and losses[0].shape == (3,)
+
+
+def _masks_from_seed(cuda, seed, n):
+    from toad_amd import functional as F_, ops
+    s1, s2, sa, sb = F_.drop_seeds(seed)
+    mk = {}
+    for name, sd, w in (("h1", s1, 512), ("h", s2, 512), ("a", sa, 384), ("b", sb, 384)):
+        mk[name] = ops.dropout_mask(n * w, F_.DROP_P, sd, cuda).reshape(n, w).cpu()
+    return mk
+
+
+@pytest.mark.parametrize("n", [300, 5000])
+def test_train_mode_dropout_matches_oracle_with_the_same_masks(cuda, n):
+    """dropout=True + train(): the in-kernel masks (hash of seed and element index, never stored) are
+    reproduced with toad_dropout_mask_f32 and fed to the oracle; forward and every gradient must agree.
+    Also: masks are ~25 % zeros scaled 1/0.75, differ between the four sites, and eval() is mask-free."""
+    from toad_amd import TOAD_fc_mtl_concat, functional as F_
+    torch.manual_seed(11)
+    model = TOAD_fc_mtl_concat(dropout=True, n_classes=18)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.05)
+    sd = model.state_dict()
+    # reference key names with dropout=True: attention_net.{0,3,6.*}; map onto the oracle's (dropout=False) names
+    rename = {"attention_net.3.": "attention_net.2.", "attention_net.6.": "attention_net.4."}
+    params = {}
+    for k, v in sd.items():
+        for a, b in rename.items():
+            if k.startswith(a):
+                k = b + k[len(a):]
+        params[k] = v.detach().clone()
+    assert set(params) == set(orc.PARAM_KEYS)
+    model.relocate(); model.train()
+    x = torch.randn(n, 1024); sex = torch.tensor([1.0]); label = torch.tensor([6]); site = torch.tensor([1])
+    torch.manual_seed(99)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # what the module will draw next
+    torch.manual_seed(99)
+    res = model(x.to(cuda), sex.to(cuda))
+    loss = orc.loss_fn(res["logits"], label.to(cuda), res["site_logits"], site.to(cuda))
+    loss.backward()
+    mk = _masks_from_seed(cuda, seed, n)
+    for name, m in mk.items():
+        vals = set(m.unique().tolist())
+        assert vals <= {0.0, float(torch.tensor(1.0) / 0.75)} and len(vals) == 2, name
+        assert abs((m == 0).float().mean().item() - 0.25) < 0.01, name
+    assert not torch.equal(mk["h1"], mk["h"]) and not torch.equal(mk["a"], mk["b"])
+    # flip-free comparison: oracle backward on the GPU-saved activations with the same masks
+    w = {k: v.detach() for k, v in model._weights().items()}
+    outs, sv = F_.mil_forward(w, x.to(cuda), sex.to(cuda), F_.DROP_P, seed)
+    assert torch.equal(outs["logits"], res["logits"].detach())  # same seed -> same masks -> bitwise same forward
+    o_out, _ = orc.forward(params, x, sex, masks=mk)
+    for k in ("logits", "site_logits", "A"):
+        assert (res[k].detach().cpu() - o_out[k]).abs().max().item() <= 1e-4, k
+    dl, ds = orc.loss_grad(outs["logits"].cpu(), label, outs["site_logits"].cpu(), site)
+    og = orc.backward(params, orc.Saved(x=x, h1=sv.h1.cpu(), h=sv.h.cpu(), p=sv.p.cpu(), a_raw=sv.a_raw.cpu(),
+                                        m=sv.m.cpu(), mcat=sv.mcat.cpu(), sex=sex, masks=mk), dl, ds)
+    inv = {}
+    for k in sd:
+        kk = k
+        for a, b in rename.items():
+            if k.startswith(a):
+                kk = b + k[len(a):]
+        inv[kk] = k
+    grads = dict(model.named_parameters())
+    for k in orc.PARAM_KEYS:
+        ref = og[k]
+        got = grads[inv[k]].grad.cpu()
+        assert (got - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-3), k
+    # a second forward draws a new seed -> different masks; eval() -> deterministic, equals the no-dropout oracle
+    res2 = model(x.to(cuda), sex.to(cuda))
+    assert not torch.equal(res2["logits"], res["logits"])
+    model.eval()
+    with torch.no_grad():
+        e1 = model(x.to(cuda), sex.to(cuda)); e2 = model(x.to(cuda), sex.to(cuda))
+    assert torch.equal(e1["logits"], e2["logits"])
+    o_eval, _ = orc.forward(params, x, sex)
+    assert (e1["logits"].cpu() - o_eval["logits"]).abs().max().item() <= 1e-4

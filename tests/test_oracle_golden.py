@@ -59,3 +59,25 @@ def test_closed_form_inputs_are_deterministic():
     p = orc.closed_form_params(18)
     assert set(p) == set(orc.PARAM_KEYS)
     assert sum(v.numel() for v in p.values()) == 1192490
+
+
+def test_oracle_dropout_backward_matches_autograd_and_reference_dropout_semantics():
+    """With explicit Dropout(0.25) multipliers the oracle's manual backward equals autograd, and the
+    multipliers are exactly what nn.Dropout applies (0 or 1/0.75), models/model_toad.py:27-29,61,64."""
+    torch.manual_seed(7)
+    params = {k: v.clone().requires_grad_(True) for k, v in orc.xavier_params(18, seed=3).items()}
+    n = 211
+    x = torch.randn(n, 1024)
+    sex = torch.tensor([0.0]); label = torch.tensor([2]); site = torch.tensor([0])
+    mk = {k: (torch.rand(n, w) >= 0.25).float() / 0.75 for k, w in (("h1", 512), ("h", 512), ("a", 384), ("b", 384))}
+    d = torch.nn.Dropout(0.25); d.train()
+    y = d(torch.ones(1000, 100))
+    assert set(y.unique().tolist()) == {0.0, 1.0 / 0.75} or set(y.unique().tolist()) == {0.0, float(torch.tensor(1.0) / 0.75)}
+    out, _ = orc.forward(params, x, sex, masks=mk)
+    orc.loss_fn(out["logits"], label, out["site_logits"], site).backward()
+    with torch.no_grad():
+        p2 = {k: v.detach() for k, v in params.items()}
+        _, _, g = orc.fwd_bwd(p2, x, sex, label, site, masks=mk)
+    for k in orc.PARAM_KEYS:
+        ref = params[k].grad
+        assert (g[k] - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1.0), k

@@ -7,28 +7,29 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TOAD_HIP_LIB", os.path.join(_HERE, "libtoad_hip.so"))   # override: kernel A/B builds only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
-P, I64, I, F, SZ = c_void_p, c_int64, c_int, c_float, c_size_t
+P, I64, I, F, SZ, U64 = c_void_p, c_int64, c_int, c_float, c_size_t, c_uint64
 
 # name -> (restype, argtypes); mirrors include/toad_hip.h one to one
 SIGNATURES = {
     "toad_abi_version": (I, []),
     "toad_last_error": (c_char_p, []),
     "toad_linear_ws_bytes": (SZ, [I64, I64, I64]),
-    "toad_linear_act_fwd_f32": (I, [P, P, P, P, I64, I64, I64, I, P, SZ, P]),
-    "toad_linear_dgrad_f32": (I, [P, P, P, P, P, I64, I64, I64, P, SZ, P]),
+    "toad_linear_act_fwd_f32": (I, [P, P, P, P, I64, I64, I64, I, F, U64, P, SZ, P]),
+    "toad_linear_dgrad_f32": (I, [P, P, P, P, F, P, I64, I64, I64, P, SZ, P]),
+    "toad_dropout_mask_f32": (I, [P, I64, F, U64, P]),
     "toad_linear_wgrad_ws_bytes": (SZ, [I64, I64, I64]),
     "toad_linear_wgrad_f32": (I, [P, P, P, P, I64, I64, I64, F, P, SZ, P]),
     "toad_transpose_f32": (I, [P, P, I64, I64, P]),
     "toad_gated_pool_ws_bytes": (SZ, [I64, I, I, I]),
-    "toad_gated_pool_fwd_f32": (I, [P, P, I64, P, P, P, P, P, P, P, SZ, I64, I, I, I, P]),
+    "toad_gated_pool_fwd_f32": (I, [P, P, I64, P, P, P, P, P, P, P, SZ, I64, I, I, I, F, U64, U64, P]),
     "toad_gated_pool_bwd_ws_bytes": (SZ, [I64, I, I, I]),
-    "toad_gated_pool_bwd_f32": (I, [P, P, I64, P, P, P, P, P, P, P, P, P, I64, P, P, P, F, P, SZ, I64, I, I, I, P]),
+    "toad_gated_pool_bwd_f32": (I, [P, P, I64, P, P, P, P, P, P, P, P, P, I64, P, P, P, F, P, SZ, I64, I, I, I, F, U64, U64, P]),
     "toad_heads_fwd_f32": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P]),
     "toad_heads_bwd_f32": (I, [P, P, P, P, P, P, P, P, P, P, P, F, I, I, P]),
     "toad_mtl_ce_fwd_bwd_f32": (I, [P, P, P, P, F, F, P, P, P, I, P]),

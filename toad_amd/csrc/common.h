@@ -35,6 +35,28 @@ __device__ __forceinline__ float row16_allreduce_sum(float v) {
     return v;
 }
 
+// ---- stateless dropout (nn.Dropout(0.25) of models/model_toad.py:27-29,61,64 in train mode) ----------
+// keep(element) = hash(seed, flat element index) >= p * 2^32 ; kept values are scaled by 1/(1-p).
+// The mask is never stored: backward recomputes it from (seed, index).
+struct DropArgs { uint64_t seed; uint32_t thresh; float scale; };   // thresh == 0 -> dropout off
+__host__ __device__ inline DropArgs make_drop(float p, uint64_t seed) {
+    DropArgs d;
+    d.seed = seed;
+    d.thresh = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
+    d.scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    return d;
+}
+__device__ __forceinline__ uint32_t drop_hash(uint64_t idx, uint64_t seed) {
+    uint32_t x = (uint32_t)idx ^ (uint32_t)seed;
+    const uint32_t y = (uint32_t)(idx >> 32) ^ (uint32_t)(seed >> 32);
+    x *= 0x9E3779B1u; x ^= x >> 15; x += y * 0x85EBCA77u;
+    x *= 0xC2B2AE3Du; x ^= x >> 13; x *= 0x27D4EB2Fu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float drop_keep(uint64_t idx, const DropArgs &d) {   // 0 or 1/(1-p)
+    return drop_hash(idx, d.seed) >= d.thresh ? d.scale : 0.f;
+}
+
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 

@@ -88,10 +88,11 @@ template <int T, int DQ /* = D/(4*LPR) float4 per lane */, int LQ /* = L/(4*LPR)
 __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
     const float *__restrict__ Pa, const float *__restrict__ Pb, int64_t ldp, const float *__restrict__ H,
     const float *__restrict__ Wc, const float *__restrict__ bc, float *__restrict__ A_raw,
-    float *__restrict__ partials, int N) {
+    float *__restrict__ partials, int N, DropArgs drop_a, DropArgs drop_b) {
     constexpr int D = DQ * 4 * LPR, L = LQ * 4 * LPR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane / LPR, c = lane % LPR;     // LPR-lane group = one row; c = float4 slot
+    const bool dropping = drop_a.thresh != 0;       // train-mode Dropout(0.25) after tanh and after sigmoid
 
     // Wc columns owned by this lane: float4 index c + LPR j
     f32x4 wc[T][DQ];
@@ -140,7 +141,15 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
         for (int j = 0; j < DQ; ++j) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float g = gate_g(xa[j][e], xb[j][e]);
+                float g;
+                if (dropping) {
+                    float a, b;
+                    gate_ab(xa[j][e], xb[j][e], a, b);
+                    const uint64_t idx = (uint64_t)rr * D + (uint64_t)((c + LPR * j) * 4 + e);
+                    g = (a * drop_keep(idx, drop_a)) * (b * drop_keep(idx, drop_b));
+                } else {
+                    g = gate_g(xa[j][e], xb[j][e]);
+                }
 #pragma unroll
                 for (int t = 0; t < T; ++t) s[t] = fmaf(g, wc[t][j][e], s[t]);
             }
@@ -297,8 +306,9 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
     const float *__restrict__ Wc, const float *__restrict__ A_raw, const float *__restrict__ stats,
     const float *__restrict__ Mp, const float *__restrict__ dM, const float *__restrict__ dA_ext,
     float *__restrict__ dPa, float *__restrict__ dPb, int64_t ldd, float *__restrict__ dH,
-    float *__restrict__ partials, int N) {
+    float *__restrict__ partials, int N, DropArgs drop_a, DropArgs drop_b) {
     constexpr int D = DQ * 4 * LPR, L = LQ * 4 * LPR;
+    const bool dropping = drop_a.thresh != 0;
     __shared__ __attribute__((aligned(16))) float s_dm[T][L];
     __shared__ __attribute__((aligned(16))) float s_wc[T][D];
     __shared__ __attribute__((aligned(16))) float s_red[NW][T][D];
@@ -398,15 +408,22 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
             for (int e = 0; e < 4; ++e) {
                 float a, b;
                 gate_ab(xa[j][e], xb[j][e], a, b);
-                const float g = a * b;
+                float ka = 1.f, kb = 1.f;           // dropout multipliers (0 or 1/(1-p)), recomputed from the seed
+                if (dropping) {
+                    const uint64_t idx = (uint64_t)rr * D + (uint64_t)((c + LPR * j) * 4 + e);
+                    ka = drop_keep(idx, drop_a);
+                    kb = drop_keep(idx, drop_b);
+                }
+                const float ad = a * ka, bd = b * kb;
+                const float g = ad * bd;
                 float dg = 0.f;
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     dg = fmaf(ds[t], w[t][e], dg);
                     dwc[t][j][e] = fmaf(ds[t], g, dwc[t][j][e]);
                 }
-                oa[e] = dg * b * (1.f - a * a);
-                ob[e] = dg * g * (1.f - b);
+                oa[e] = dg * bd * ka * (1.f - a * a);
+                ob[e] = dg * ad * kb * b * (1.f - b);
             }
             if (valid) {
                 st4(dpa + 4 * LPR * j, oa);
@@ -488,11 +505,12 @@ static bool shape_ok(int L, int D, int T) {
 
 template <bool POOL>
 static void launch_fwd(int L, int D, int T, int grid, hipStream_t st, const float *Pa, const float *Pb, int64_t ldp,
-                       const float *H, const float *Wc, const float *bc, float *A_raw, float *partials, int N) {
+                       const float *H, const float *Wc, const float *bc, float *A_raw, float *partials, int N,
+                       DropArgs da, DropArgs db) {
 #define TOAD_FWD_CASE(TT, DD, LL)                                                                             \
     if (T == TT && D == DD && L == LL) {                                                                      \
         hipLaunchKernelGGL((gated_pool_fwd_kernel<TT, DD / (4 * LPR), LL / (4 * LPR), POOL>), dim3(grid), dim3(POOL_THREADS), 0, st, \
-                           Pa, Pb, ldp, H, Wc, bc, A_raw, partials, N);                                       \
+                           Pa, Pb, ldp, H, Wc, bc, A_raw, partials, N, da, db);                               \
         return;                                                                                               \
     }
     TOAD_FWD_CASE(2, 384, 512)
@@ -509,11 +527,11 @@ static void launch_fwd(int L, int D, int T, int grid, hipStream_t st, const floa
 static void launch_bwd(int L, int D, int T, int grid, hipStream_t st, const float *Pa, const float *Pb, int64_t ldp,
                        const float *H, const float *Wc, const float *A_raw, const float *stats, const float *M,
                        const float *dM, const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH,
-                       float *partials, int N) {
+                       float *partials, int N, DropArgs da, DropArgs db) {
 #define TOAD_BWD_CASE(TT, DD, LL)                                                                             \
     if (T == TT && D == DD && L == LL) {                                                                      \
         hipLaunchKernelGGL((gated_pool_bwd_kernel<TT, DD / (4 * LPR), LL / (4 * LPR)>), dim3(grid), dim3(POOL_THREADS), 0, st, Pa, \
-                           Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, partials, N);      \
+                           Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, partials, N, da, db); \
         return;                                                                                               \
     }
     TOAD_BWD_CASE(2, 384, 512)
@@ -538,8 +556,11 @@ extern "C" size_t toad_gated_pool_ws_bytes(int64_t N, int L, int D, int T) {
 
 extern "C" int toad_gated_pool_fwd_f32(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc,
                                         const float *bc, float *A_raw, float *M, float *stats, void *ws,
-                                        size_t ws_bytes, int64_t N, int L, int D, int T, void *stream) {
+                                        size_t ws_bytes, int64_t N, int L, int D, int T, float drop_p,
+                                        uint64_t seed_a, uint64_t seed_b, void *stream) {
     const char *what = "toad_gated_pool_fwd_f32";
+    if (!(drop_p >= 0.f && drop_p < 1.f)) { set_error("%s: drop_p must be in [0,1)", what); return TOAD_EINVAL; }
+    const DropArgs da = make_drop(drop_p, seed_a), db = make_drop(drop_p, seed_b);
     if (!Pa || !Pb || !Wc || !bc || !A_raw) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (N <= 0 || N > INT32_MAX - 64) { set_error("%s: bad N=%lld", what, (long long)N); return TOAD_EINVAL; }
     if (!shape_ok(L, D, T)) { set_error("%s: unsupported shape L=%d D=%d T=%d (T in {1,2}, D in {256,384}, L in {512,1024})", what, L, D, T); return TOAD_ESHAPE; }
@@ -549,13 +570,13 @@ extern "C" int toad_gated_pool_fwd_f32(const float *Pa, const float *Pb, int64_t
     const int grid = pool_grid(N);
     if (!H) {
         if (M || stats) { set_error("%s: M/stats requested without H", what); return TOAD_EINVAL; }
-        launch_fwd<false>(L, D, T, grid, st, Pa, Pb, ldp, nullptr, Wc, bc, A_raw, nullptr, (int)N);
+        launch_fwd<false>(L, D, T, grid, st, Pa, Pb, ldp, nullptr, Wc, bc, A_raw, nullptr, (int)N, da, db);
         return check_launch(what);
     }
     if (!M || !stats || !ws) { set_error("%s: null output/workspace", what); return TOAD_EINVAL; }
     if (!aligned16(ws)) { set_error("%s: workspace must be 16-byte aligned", what); return TOAD_EALIGN; }
     if (ws_bytes < toad_gated_pool_ws_bytes(N, L, D, T)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
-    launch_fwd<true>(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, bc, A_raw, (float *)ws, (int)N);
+    launch_fwd<true>(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, bc, A_raw, (float *)ws, (int)N, da, db);
     int rc = check_launch(what);
     if (rc) return rc;
     hipLaunchKernelGGL(gated_pool_combine_kernel, dim3(T * L / 8), dim3(256), 0, st, (const float *)ws, grid, L, T, M, stats);
@@ -571,8 +592,11 @@ extern "C" int toad_gated_pool_bwd_f32(const float *Pa, const float *Pb, int64_t
                                         const float *A_raw, const float *stats, const float *M, const float *dM,
                                         const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH,
                                         float *dWc, float *dbc, float beta, void *ws, size_t ws_bytes, int64_t N,
-                                        int L, int D, int T, void *stream) {
+                                        int L, int D, int T, float drop_p, uint64_t seed_a, uint64_t seed_b,
+                                        void *stream) {
     const char *what = "toad_gated_pool_bwd_f32";
+    if (!(drop_p >= 0.f && drop_p < 1.f)) { set_error("%s: drop_p must be in [0,1)", what); return TOAD_EINVAL; }
+    const DropArgs da = make_drop(drop_p, seed_a), db = make_drop(drop_p, seed_b);
     if (!Pa || !Pb || !H || !Wc || !A_raw || !stats || !M || !dM || !dPa || !dPb || !dH || !dWc || !dbc || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (N <= 0 || N > INT32_MAX - 64) { set_error("%s: bad N", what); return TOAD_EINVAL; }
     if (!shape_ok(L, D, T)) { set_error("%s: unsupported shape L=%d D=%d T=%d", what, L, D, T); return TOAD_ESHAPE; }
@@ -581,7 +605,7 @@ extern "C" int toad_gated_pool_bwd_f32(const float *Pa, const float *Pb, int64_t
     if (ws_bytes < toad_gated_pool_bwd_ws_bytes(N, L, D, T)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     const int grid = pool_grid(N);
-    launch_bwd(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, (float *)ws, (int)N);
+    launch_bwd(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, (float *)ws, (int)N, da, db);
     int rc = check_launch(what);
     if (rc) return rc;
     const int n = T * D + T;

@@ -33,6 +33,9 @@ constexpr int TN_LD = 128;
 constexpr int TN_TILE = BK * TN_LD;
 constexpr int TN_SMEM = 2 * 2 * TN_TILE * (int)sizeof(float);   // 65,536 B
 
+// epilogue scalars shared by every NT kernel (plain scalars only: pointers stay direct kernel arguments)
+struct EpiScalars { int relu; float mask_scale; DropArgs drop; };
+
 // XCD-aware block -> tile map: all column tiles of one row tile run on the same XCD (same L2),
 // back to back, so the A panel is fetched from HBM once and re-read from L2.
 __device__ __forceinline__ bool map_tile(int tiles_m, int tiles_n, int &tm, int &tn) {
@@ -49,9 +52,10 @@ __device__ __forceinline__ bool map_tile(int tiles_m, int tiles_n, int &tm, int 
 __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(
     const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
     float *C, int64_t ldc, int M, int N, int K,
-    const float *__restrict__ bias, int relu, const float *addend, const float *__restrict__ mask_src,
+    const float *__restrict__ bias, EpiScalars es, const float *addend, const float *__restrict__ mask_src,
     int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int relu = es.relu;
     int tm, tn;
     if (!map_tile(tiles_m, tiles_n, tm, tn)) return;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -200,7 +204,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(
                 float v = acc[a][b][r] + bv;
                 if (addend) v += add[r];
                 if (relu) v = v > 0.f ? v : 0.f;
-                if (mask_src) v = msk[r] > 0.f ? v : 0.f;
+                if (es.drop.thresh) v *= drop_keep((uint64_t)row * (uint64_t)N + (uint64_t)col, es.drop);
+                if (mask_src) v = msk[r] > 0.f ? v * es.mask_scale : 0.f;
                 if (cok && row < M) C[(int64_t)row * ldc + col] = v;
             }
         }
@@ -261,20 +266,26 @@ __host__ __device__ inline NtPlan nt_plan(int xcd, int tiles_m, int tiles_n, int
 // NOTE: bias/addend/mask are passed to the kernels as DIRECT pointer arguments. Inside a by-value struct
 // hipcc does not infer the global address space, emits FLAT loads, and a pending FLAT access makes it
 // put `s_waitcnt vmcnt(0) lgkmcnt(0)` in front of every LDS access that follows (found the hard way).
-__device__ __forceinline__ f32x4 apply_epilogue(f32x4 v, int relu, const float *add_p, const float *msk_p, f32x4 bv) {
+__device__ __forceinline__ f32x4 apply_epilogue(f32x4 v, const EpiScalars &e, const float *add_p, const float *msk_p, f32x4 bv,
+                                                uint64_t flat_idx) {
     v += bv;
     if (add_p) v += ld4(add_p);
-    if (relu) { v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f; v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f; }
-    if (msk_p) {
+    if (e.relu) { v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f; v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f; }
+    if (e.drop.thresh) {               // forward dropout after the activation
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= drop_keep(flat_idx + k, e.drop);
+    }
+    if (msk_p) {                       // backward: relu (and dropout) mask of the saved activation, times 1/(1-p)
         const f32x4 m = ld4(msk_p);
-        v[0] = m[0] > 0.f ? v[0] : 0.f; v[1] = m[1] > 0.f ? v[1] : 0.f; v[2] = m[2] > 0.f ? v[2] : 0.f; v[3] = m[3] > 0.f ? v[3] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = m[k] > 0.f ? v[k] * e.mask_scale : 0.f;
     }
     return v;
 }
 
 __global__ __launch_bounds__(512, 2) void gemm_nt_f32_big_kernel(
     const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
-    float *C, int64_t ldc, int M, int N, int K, const float *__restrict__ bias, int relu, const float *addend,
+    float *C, int64_t ldc, int M, int N, int K, const float *__restrict__ bias, EpiScalars es, const float *addend,
     const float *__restrict__ mask_src, float *__restrict__ slabs, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -411,8 +422,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f32_big_kernel(
                     st4(slab + urow * PB + svoff, v);
                 } else if (cok && (m0 + urow + hi4) < M) {
                     const int64_t uoff = (int64_t)(m0 + urow) * ldc + ucol;            // wave-uniform
-                    st4(C + uoff + voff, apply_epilogue(v, relu, addend ? addend + uoff + voff : nullptr,
-                                                        mask_src ? mask_src + uoff + voff : nullptr, bv));
+                    st4(C + uoff + voff, apply_epilogue(v, es, addend ? addend + uoff + voff : nullptr,
+                                                        mask_src ? mask_src + uoff + voff : nullptr, bv,
+                                                        (uint64_t)(m0 + urow + hi4) * (uint64_t)N + (uint64_t)(ucol + li4)));
                 }
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most 4 rows of loads in flight: bounded registers
             }
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f32_big_kernel(
 // Remainder tiles: C tile = epilogue(sum of the g K-slice slabs), fixed order. grid = (16, 31, 8):
 // x = 16-row strip group of the tile, y = remainder tile index of the XCD, z = XCD.
 __global__ __launch_bounds__(256) void nt_fixup_kernel(const float *__restrict__ slabs, float *C, int64_t ldc, int M, int N,
-                                                        int K, const float *__restrict__ bias, int relu, const float *addend,
+                                                        int K, const float *__restrict__ bias, EpiScalars es, const float *addend,
                                                         const float *__restrict__ mask_src, int tiles_m, int tiles_n) {
     const int xcd = blockIdx.z, tr = blockIdx.y;
     const NtPlan pl = nt_plan(xcd, tiles_m, tiles_n, K / BK);
@@ -478,7 +490,8 @@ __global__ __launch_bounds__(256) void nt_fixup_kernel(const float *__restrict__
         for (int p = 1; p < pl.g; ++p)
             v += ld4(slabs + ((int64_t)(xcd + kNumXCD * (tr * pl.g + p)) * PB + lrow) * PB + c4 * 4);
         const int64_t off = (int64_t)(m0 + lrow) * ldc + col;
-        st4(C + off, apply_epilogue(v, relu, addend ? addend + off : nullptr, mask_src ? mask_src + off : nullptr, bv));
+        st4(C + off, apply_epilogue(v, es, addend ? addend + off : nullptr, mask_src ? mask_src + off : nullptr, bv,
+                                    (uint64_t)(m0 + lrow) * (uint64_t)N + (uint64_t)col));
     }
 }
 
@@ -864,7 +877,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 // host side
 // ------------------------------------------------------------------------------------------
 static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
-                     int64_t M, int64_t N, int64_t K, const float *bias, int relu, const float *addend,
+                     int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
                      const float *mask_src, void *ws, hipStream_t st, const char *what) {
     if (M <= 0 || N <= 0 || K <= 0) { set_error("%s: non-positive dimension", what); return TOAD_EINVAL; }
     if (M > INT32_MAX - BM || N > INT32_MAX - BN || K > INT32_MAX - BK) { set_error("%s: dimension too large", what); return TOAD_ESHAPE; }
@@ -887,14 +900,14 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
         (uint64_t)N * ldb * 4 < (1ull << 32)) {
         const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
         hipLaunchKernelGGL(gemm_nt_f32_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, A, lda, B, ldb, C, ldc, (int)M,
-                           (int)N, (int)K, bias, relu, addend, mask_src, (float *)ws, tiles_m, tiles_n);
+                           (int)N, (int)K, bias, es, addend, mask_src, (float *)ws, tiles_m, tiles_n);
         int rc = check_launch(what);
         if (rc) return rc;
         bool any_rem = false;
         for (int x = 0; x < kNumXCD; ++x) any_rem |= nt_plan(x, tiles_m, tiles_n, (int)(K / BK)).rem > 0;
         if (any_rem) {
             hipLaunchKernelGGL(nt_fixup_kernel, dim3(16, PB_BLOCKS_PER_XCD - 1, kNumXCD), dim3(256), 0, st, (const float *)ws, C,
-                               ldc, (int)M, (int)N, (int)K, bias, relu, addend, mask_src, tiles_m, tiles_n);
+                               ldc, (int)M, (int)N, (int)K, bias, es, addend, mask_src, tiles_m, tiles_n);
             rc = check_launch(what);
         }
         return rc;
@@ -903,7 +916,7 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     const int grid = kNumXCD * ((tiles_m + kNumXCD - 1) / kNumXCD) * tiles_n;
     hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3(grid), dim3(256), NT_SMEM, st, A, lda, B, ldb, C, ldc, (int)M, (int)N,
-                       (int)K, bias, relu, addend, mask_src, tiles_m, tiles_n);
+                       (int)K, bias, es, addend, mask_src, tiles_m, tiles_n);
     return check_launch(what);
 }
 
@@ -953,22 +966,26 @@ static int check_ws(void *ws, size_t ws_bytes, int64_t M, int64_t N, int64_t K, 
 }
 
 extern "C" int toad_linear_act_fwd_f32(const float *X, const float *W, const float *bias, float *Y, int64_t M,
-                                        int64_t K, int64_t N, int act, void *ws, size_t ws_bytes, void *stream) {
+                                        int64_t K, int64_t N, int act, float drop_p, uint64_t drop_seed, void *ws,
+                                        size_t ws_bytes, void *stream) {
     const char *what = "toad_linear_act_fwd_f32";
     if (!X || !W || !Y) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (act != TOAD_ACT_NONE && act != TOAD_ACT_RELU) { set_error("%s: bad act %d", what, act); return TOAD_EINVAL; }
+    if (!(drop_p >= 0.f && drop_p < 1.f)) { set_error("%s: drop_p must be in [0,1)", what); return TOAD_EINVAL; }
     if (int rc = check_ws(ws, ws_bytes, M, N, K, what)) return rc;
-    return launch_nt(X, K, W, K, Y, N, M, N, K, bias, act == TOAD_ACT_RELU, nullptr, nullptr, ws, (hipStream_t)stream, what);
+    EpiScalars es{act == TOAD_ACT_RELU, 1.f, make_drop(drop_p, drop_seed)};
+    return launch_nt(X, K, W, K, Y, N, M, N, K, bias, es, nullptr, nullptr, ws, (hipStream_t)stream, what);
 }
 
 extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend, const float *relu_src,
-                                      float *dX, int64_t M, int64_t N, int64_t K, void *ws, size_t ws_bytes,
-                                      void *stream) {
+                                      float mask_scale, float *dX, int64_t M, int64_t N, int64_t K, void *ws,
+                                      size_t ws_bytes, void *stream) {
     const char *what = "toad_linear_dgrad_f32";
     if (!dY || !WT || !dX) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (int rc = check_ws(ws, ws_bytes, M, K, N, what)) return rc;
     // dX[M,K] = dY[M,N] . WT[K,N]^T : an NT product with reduction dim N
-    return launch_nt(dY, N, WT, N, dX, K, M, K, N, nullptr, 0, addend, relu_src, ws, (hipStream_t)stream, what);
+    EpiScalars es{0, mask_scale, make_drop(0.f, 0)};
+    return launch_nt(dY, N, WT, N, dX, K, M, K, N, nullptr, es, addend, relu_src, ws, (hipStream_t)stream, what);
 }
 
 static bool tn_big_ok(int64_t M, int64_t N, int64_t K) {
@@ -1039,4 +1056,17 @@ extern "C" int toad_transpose_f32(const float *in, float *out, int64_t rows, int
     dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, (int)rows, (int)cols);
     return check_launch("toad_transpose_f32");
+}
+
+// mask[e] = 0 or 1/(1-p) for flat element e (the multiplier the kernels apply): test/debug helper
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float *out, int64_t n, DropArgs d) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+        out[e] = d.thresh ? drop_keep((uint64_t)e, d) : 1.f;
+}
+extern "C" int toad_dropout_mask_f32(float *out, int64_t n, float drop_p, uint64_t drop_seed, void *stream) {
+    if (!out || n <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) { set_error("toad_dropout_mask_f32: bad argument"); return TOAD_EINVAL; }
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, n, make_drop(drop_p, drop_seed));
+    return check_launch("toad_dropout_mask_f32");
 }

@@ -43,16 +43,27 @@ def _require_cuda(t: torch.Tensor, what: str) -> None:
             "Call model.relocate() and move the inputs to the GPU.")
 
 
+def _draw_dropout(active: bool):
+    """(drop_p, seed) for one forward. Train-mode Dropout(0.25) masks are a stateless hash of (seed, element
+    index) inside the kernels; the seed is drawn from torch's CPU generator, so torch.manual_seed /
+    seed_torch (main_mtl_concat.py:109-119) make runs reproducible. No host-device sync is involved."""
+    if not active:
+        return 0.0, 0
+    return F_.DROP_P, int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
 class _ScoresFn(torch.autograd.Function):
     """Standalone Attn_Net_Gated: A = (tanh(xWa^T+ba) * sigmoid(xWb^T+bb)) Wc^T + bc."""
 
     @staticmethod
-    def forward(ctx, x, wa, ba, wb, bb, wc, bc):
+    def forward(ctx, x, wa, ba, wb, bb, wc, bc, drop_p, seed):
         wab, bab = torch.cat([wa, wb], 0), torch.cat([ba, bb], 0)
         p = ops.linear_act_fwd(x, wab, bab, ops.ACT_NONE)
-        a_raw, _, _ = ops.gated_pool_fwd(p, wa.shape[0], None, wc, bc)
+        _, _, sa, sb = F_.drop_seeds(seed)
+        a_raw, _, _ = ops.gated_pool_fwd(p, wa.shape[0], None, wc, bc, drop_p, sa, sb)
         ctx.save_for_backward(x, p, wab, wc)
         ctx.need_dx = x.requires_grad
+        ctx.drop = (drop_p, sa, sb)
         return a_raw
 
     @staticmethod
@@ -64,11 +75,13 @@ class _ScoresFn(torch.autograd.Function):
         # reuse the pooled backward with softmax weight p == 0 (stats = (0, inf)): dS = dA
         stats = torch.tensor([[0.0, float("inf")]] * t, device=dev)
         zeros = torch.zeros((t, l), device=dev)
+        if l not in (512, 1024):
+            raise NotImplementedError("Attn_Net_Gated backward supports L in {512, 1024}")
         dp, _, dwc, dbc = ops.gated_pool_bwd(p, d, x, wc, torch.zeros((n, t), device=dev), stats, zeros, zeros,
-                                             da.contiguous())
+                                             da.contiguous(), drop_p=ctx.drop[0], seed_a=ctx.drop[1], seed_b=ctx.drop[2])
         dwab, dbab = ops.linear_wgrad(dp, x)
         dx = ops.linear_dgrad(dp, ops.transpose(wab)) if ctx.need_dx else None
-        return dx, dwab[:d], dbab[:d], dwab[d:], dbab[d:], dwc, dbc
+        return dx, dwab[:d], dbab[:d], dwab[d:], dbab[d:], dwc, dbc, None, None
 
 
 class Attn_Net_Gated(nn.Module):
@@ -88,12 +101,10 @@ class Attn_Net_Gated(nn.Module):
 
     def forward(self, x):
         _require_cuda(x, "x")
-        if self._dropout and self.training:
-            raise NotImplementedError("toad_amd: in-kernel dropout masks are not implemented yet; "
-                                      "use dropout=False or model.eval()")
+        drop_p, seed = _draw_dropout(self._dropout and self.training)
         A = _ScoresFn.apply(x.contiguous(), self.attention_a[0].weight, self.attention_a[0].bias,
                             self.attention_b[0].weight, self.attention_b[0].bias,
-                            self.attention_c.weight, self.attention_c.bias)
+                            self.attention_c.weight, self.attention_c.bias, drop_p, seed)
         return A, x
 
 
@@ -205,21 +216,19 @@ class TOAD_fc_mtl_concat(nn.Module):
 
     def forward(self, h, sex, return_features=False, attention_only=False):
         _require_cuda(h, "h")
-        if self._dropout and self.training:
-            raise NotImplementedError("toad_amd: in-kernel dropout masks are not implemented yet; "
-                                      "use dropout=False or model.eval()")
+        drop_p, seed = _draw_dropout(self._dropout and self.training)
         w = self._weights()
         _require_cuda(w["w1"], "model parameters")
         h = h.contiguous()
         if attention_only:
             with torch.no_grad():
-                a_raw = F_.attention_scores({k: v.detach() for k, v in w.items()}, h)
+                a_raw = F_.attention_scores({k: v.detach() for k, v in w.items()}, h, drop_p, seed)
             return a_raw.t()[0]                                   # model_toad.py:92-94: raw task-0 scores, [N]
         _require_cuda(sex, "sex")
         sex = sex.to(torch.float32).reshape(1).contiguous()
         sp = [w[k] for k in F_.SLOTS]
         logits, site_logits, a_nt, feats, y_prob, y_hat, site_prob, site_hat = F_.ToadMIL.apply(
-            h, sex, *sp, w["wab"], w["bab"])
+            h, sex, *sp, w["wab"], w["bab"], drop_p, seed)
         results_dict = {}
         if return_features:
             results_dict.update({"features": feats})              # M after the sex concat, [2, L+1]

@@ -76,8 +76,8 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
-def linear_act_fwd(x, w, b, act: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Y = act(X W^T + b); X [M,K], W [N,K], b [N] or None."""
+def linear_act_fwd(x, w, b, act: int, out: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
+    """Y = dropout_p(act(X W^T + b)); X [M,K], W [N,K], b [N] or None. drop_p = 0 disables dropout."""
     _chk(x, "x"); _chk(w, "w"); _chk(b, "b", allow_none=True)
     m, k = x.shape
     n, k2 = w.shape
@@ -88,8 +88,8 @@ def linear_act_fwd(x, w, b, act: int, out: Optional[torch.Tensor] = None) -> tor
     lib = _lib.load()
     ws = _ws(lib.toad_linear_ws_bytes(m, n, k), x.device)
     with _timed("gemm_fwd"):
-        _lib.check(lib.toad_linear_act_fwd_f32(_p(x), _p(w), _p(b), _p(y), m, k, n, act, _p(ws), ws.numel(), _stream()),
-                   "toad_linear_act_fwd_f32")
+        _lib.check(lib.toad_linear_act_fwd_f32(_p(x), _p(w), _p(b), _p(y), m, k, n, act, float(drop_p), int(drop_seed),
+                                               _p(ws), ws.numel(), _stream()), "toad_linear_act_fwd_f32")
     return y
 
 
@@ -101,8 +101,8 @@ def transpose(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def linear_dgrad(dy, wt, addend=None, relu_src=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dX = (dY W + addend) * (relu_src > 0); dY [M,N], wt = W^T [K,N]."""
+def linear_dgrad(dy, wt, addend=None, relu_src=None, out: Optional[torch.Tensor] = None, mask_scale: float = 1.0) -> torch.Tensor:
+    """dX = (dY W + addend) * (relu_src > 0) * mask_scale; dY [M,N], wt = W^T [K,N]."""
     _chk(dy, "dy"); _chk(wt, "wt"); _chk(addend, "addend", allow_none=True); _chk(relu_src, "relu_src", allow_none=True)
     m, n = dy.shape
     k, n2 = wt.shape
@@ -116,8 +116,8 @@ def linear_dgrad(dy, wt, addend=None, relu_src=None, out: Optional[torch.Tensor]
     lib = _lib.load()
     ws = _ws(lib.toad_linear_ws_bytes(m, k, n), dy.device)
     with _timed("gemm_dgrad"):
-        _lib.check(lib.toad_linear_dgrad_f32(_p(dy), _p(wt), _p(addend), _p(relu_src), _p(dx), m, n, k, _p(ws), ws.numel(),
-                                             _stream()), "toad_linear_dgrad_f32")
+        _lib.check(lib.toad_linear_dgrad_f32(_p(dy), _p(wt), _p(addend), _p(relu_src), float(mask_scale), _p(dx), m, n, k,
+                                             _p(ws), ws.numel(), _stream()), "toad_linear_dgrad_f32")
     return dx
 
 
@@ -143,7 +143,14 @@ def linear_wgrad(dy, x, dw: Optional[torch.Tensor] = None, db: Optional[torch.Te
     return dw, db
 
 
-def gated_pool_fwd(p: torch.Tensor, d: int, h: Optional[torch.Tensor], wc, bc):
+def dropout_mask(n: int, drop_p: float, drop_seed: int, device) -> torch.Tensor:
+    """The multiplier (0 or 1/(1-p)) the kernels apply to flat element e under ``drop_seed`` (never stored by them)."""
+    out = torch.empty((n,), dtype=torch.float32, device=device)
+    _lib.check(_lib.load().toad_dropout_mask_f32(_p(out), n, float(drop_p), int(drop_seed), _stream()), "toad_dropout_mask_f32")
+    return out
+
+
+def gated_pool_fwd(p: torch.Tensor, d: int, h: Optional[torch.Tensor], wc, bc, drop_p: float = 0.0, seed_a: int = 0, seed_b: int = 0):
     """p = [N, 2D] stacked pre-activations (Pa | Pb). Returns (A_raw [N,T], M [T,L], stats [T,2]);
     with h=None only A_raw is computed (attention_only)."""
     _chk(p, "p"); _chk(h, "h", allow_none=True); _chk(wc, "wc"); _chk(bc, "bc")
@@ -156,7 +163,8 @@ def gated_pool_fwd(p: torch.Tensor, d: int, h: Optional[torch.Tensor], wc, bc):
     pb_ptr = p.data_ptr() + 4 * d
     if h is None:
         _lib.check(lib.toad_gated_pool_fwd_f32(_p(p), pb_ptr, ldp, None, _p(wc), _p(bc), _p(a_raw), None, None, None, 0,
-                                               n, 512, d, t, _stream()), "toad_gated_pool_fwd_f32")
+                                               n, 512, d, t, float(drop_p), int(seed_a), int(seed_b), _stream()),
+                   "toad_gated_pool_fwd_f32")
         return a_raw, None, None
     l = h.shape[1]
     if h.shape[0] != n:
@@ -166,12 +174,14 @@ def gated_pool_fwd(p: torch.Tensor, d: int, h: Optional[torch.Tensor], wc, bc):
     ws = _ws(lib.toad_gated_pool_ws_bytes(n, l, d, t), p.device)
     with _timed("pool_fwd"):
         _lib.check(lib.toad_gated_pool_fwd_f32(_p(p), pb_ptr, ldp, _p(h), _p(wc), _p(bc), _p(a_raw), _p(m), _p(stats),
-                                               _p(ws), ws.numel(), n, l, d, t, _stream()), "toad_gated_pool_fwd_f32")
+                                               _p(ws), ws.numel(), n, l, d, t, float(drop_p), int(seed_a), int(seed_b),
+                                               _stream()), "toad_gated_pool_fwd_f32")
     return a_raw, m, stats
 
 
 def gated_pool_bwd(p, d: int, h, wc, a_raw, stats, m, dm, da_ext=None, dwc=None, dbc=None, beta: float = 0.0,
-                   dp: Optional[torch.Tensor] = None, dh: Optional[torch.Tensor] = None):
+                   dp: Optional[torch.Tensor] = None, dh: Optional[torch.Tensor] = None,
+                   drop_p: float = 0.0, seed_a: int = 0, seed_b: int = 0):
     """Returns (dP [N,2D], dH_pool [N,L], dWc [T,D], dbc [T])."""
     for t_, nm in ((p, "p"), (h, "h"), (wc, "wc"), (a_raw, "a_raw"), (stats, "stats"), (m, "m"), (dm, "dm")):
         _chk(t_, nm)
@@ -193,7 +203,8 @@ def gated_pool_bwd(p, d: int, h, wc, a_raw, stats, m, dm, da_ext=None, dwc=None,
     with _timed("pool_bwd"):
         _lib.check(lib.toad_gated_pool_bwd_f32(_p(p), p.data_ptr() + 4 * d, ldp, _p(h), _p(wc), _p(a_raw), _p(stats), _p(m),
                                                _p(dm), _p(da_ext), _p(dp), dp.data_ptr() + 4 * d, ldp, _p(dh), _p(dwc),
-                                               _p(dbc), float(beta), _p(ws), ws.numel(), n, l, d, t, _stream()),
+                                               _p(dbc), float(beta), _p(ws), ws.numel(), n, l, d, t, float(drop_p),
+                                               int(seed_a), int(seed_b), _stream()),
                    "toad_gated_pool_bwd_f32")
     return dp, dh, dwc, dbc
 
