@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--patches", type=int, default=100_000)
     ap.add_argument("--slides-per-rank", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="plumbing test only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,11 +132,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from toad_amd import TOAD_fc_mtl_concat, ops
     from toad_amd.dp import SlideShardedDP
@@ -201,11 +209,11 @@ def main():
                                    f"{spr} x {n}-patch x 1024-d N(0,1) bag per GPU per step, bags resident in HBM",
                        "patches_per_slide": n, "slides_per_step": global_slides,
                        "parallelism": f"slide-sharded dp{world}, one {4 * model.flat_parameters().numel() / 1e6:.2f} MB grad all-reduce/step"},
-            "roofline": {"bound": "hbm", "kernel": "gated_pool_fwd_kernel<2,6,8,true> + gated_pool_combine_kernel",
+            "roofline": {"bound": "hbm", "kernel": "gated_pool_fwd_kernel<2,3,4,true> + gated_pool_combine_kernel",
                          "achieved": round(pool_bw / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(pool_bw / HBM_PEAK, 4), "traffic": None,
                          "algorithmic_bytes": pool_fwd_bytes(n), "us_per_launch": round(pool_t * 1e6, 2)},
-            "roofline_mfma": {"bound": "mfma", "kernel": "gemm_nt_f32_kernel x5 + gemm_tn_f32_kernel x3 (+slab reduce)",
+            "roofline_mfma": {"bound": "mfma", "kernel": "gemm_nt_f32_big_kernel x5 (+nt_fixup) + gemm_tn_f32_big_kernel x3 (+slab_reduce)",
                               "achieved": round(gemm_tf / 1e12, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                               "frac": round(gemm_tf / MFMA_F32_PEAK, 4), "traffic": None,
                               "algorithmic_flops": GEMM_FLOP_PER_PATCH * n, "us_per_slide": round(gemm_t * 1e6, 1)},
