@@ -150,7 +150,7 @@ def main():
     model = TOAD_fc_mtl_concat(dropout=False, n_classes=C)
     model.relocate()
     model.train()
-    dp = SlideShardedDP(model, lambda ps: torch.optim.Adam(ps, lr=1e-4, weight_decay=1e-5, fused=True))
+    dp = SlideShardedDP(model, {"lr": 1e-4, "weight_decay": 1e-5})      # get_optim defaults (main_mtl_concat.py:93-96), HIP flat Adam
 
     n = args.patches
     spr = args.slides_per_rank

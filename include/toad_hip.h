@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOAD_ABI_VERSION 3
+#define TOAD_ABI_VERSION 5
 
 enum { TOAD_OK = 0, TOAD_EINVAL = -1, TOAD_ESHAPE = -2, TOAD_EWORKSPACE = -3, TOAD_EALIGN = -4 };
 enum { TOAD_ACT_NONE = 0, TOAD_ACT_RELU = 1 };
@@ -148,6 +148,33 @@ int toad_mtl_ce_fwd_bwd_f32(const float *logits, const float *site_logits,
                             float w_cls, float w_site,
                             float *loss_out, float *dlogits, float *dsite,
                             int C, void *stream);
+
+/* Adam over a flat fp32 buffer (n % 4 == 0), identical update to torch.optim.Adam(lr, betas, eps, weight_decay)
+ * as built by the reference's get_optim (utils/utils.py:63-70); `step` counts from 1. One launch. */
+int toad_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int64_t step, void *stream);
+
+/* ---- Whole per-slide training step ------------------------------------------------------ */
+
+/* One call = model(data, sex) + weighted CE + loss.backward() of the reference train loop
+ * (utils/core_utils_mtl_concat.py:206,213-215,231) for TOAD_fc_mtl_concat(size_arg="big"), sequenced in
+ * C++ over a caller-owned arena (toad_mil_step_ws_bytes) with the kernels above, in the same order as the
+ * per-op path: no host round trips or allocations between launches.
+ *   params / grads : 12 device pointers each, slots w1 b1 w2 b2 wab bab wc bc wcls bcls wsite bsite
+ *                    (wab = [Wa;Wb] stacked [2D,512], bab = [ba;bb]); grads = beta*grads + d loss/d param.
+ *   sex / label / site : one device float / int64 / int64.  loss_out[3] = (loss, cls CE, site CE).
+ *   logits_out [C], site_logits_out [2] : optional copies of the logits.
+ *   drop_p, seed : train-mode Dropout(drop_p) masks (0 = off), four streams derived from `seed`.
+ *   events : NULL, or 18 hipEvent_t recorded around the fused pool forward ([0],[1]) and the eight GEMM
+ *            calls ([2+2i],[3+2i]) - used by bench.py for its roofline figures. */
+size_t toad_mil_step_ws_bytes(int64_t N, int C, int D);
+int toad_mil_step_f32(const float *const *params, float *const *grads, float beta, const float *X,
+                      const float *sex, const int64_t *label, const int64_t *site,
+                      float w_cls, float w_site, int64_t N, int C, int D,
+                      float drop_p, uint64_t seed,
+                      float *loss_out, float *logits_out, float *site_logits_out,
+                      void *ws, size_t ws_bytes, void **events, void *stream);
 
 #ifdef __cplusplus
 }

@@ -279,3 +279,45 @@ def test_train_mode_dropout_matches_oracle_with_the_same_masks(cuda, n):
     assert torch.equal(e1["logits"], e2["logits"])
     o_eval, _ = orc.forward(params, x, sex)
     assert (e1["logits"].cpu() - o_eval["logits"]).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("n,drop", [(1, 0.0), (777, 0.0), (4000, 0.25)])
+def test_fused_step_entry_is_bitwise_the_per_op_path(cuda, n, drop):
+    """toad_mil_step_f32 (one C call) == mil_forward + mtl_ce + mil_backward (per-op calls): same kernels, same
+    order -> bitwise-equal loss and gradients, with and without dropout, and beta-accumulation works."""
+    from toad_amd import TOAD_fc_mtl_concat, functional as F_, ops
+    torch.manual_seed(21)
+    model = TOAD_fc_mtl_concat(n_classes=18); model.relocate()
+    w = {k: v.detach() for k, v in model._weights().items()}
+    x = torch.randn(n, 1024, device=cuda); sex = torch.ones(1, device=cuda)
+    label = torch.tensor([9], device=cuda); site = torch.tensor([0], device=cuda)
+    seed = 123456789
+    outs, saved = F_.mil_forward(w, x, sex, drop, seed)
+    lossv, dl, ds = ops.mtl_ce_fwd_bwd(outs["logits"], outs["site_logits"], label, site, 0.75, 0.25)
+    g, _ = F_.mil_backward(w, saved, dl, ds)
+    dest = {k: torch.full_like(w[k], 2.0) for k in ops.STEP_SLOTS}
+    loss2, lg, slg = ops.mil_step(w, dest, 0.0, x, sex, label, site, 0.75, 0.25, drop, seed, want_logits=True)
+    assert torch.equal(loss2, lossv) and torch.equal(lg, outs["logits"]) and torch.equal(slg, outs["site_logits"])
+    d = w["wa"].shape[0]
+    ref = dict(g); ref["wab"] = torch.cat([g["wa"], g["wb"]], 0); ref["bab"] = torch.cat([g["ba"], g["bb"]], 0)
+    for k in ops.STEP_SLOTS:
+        assert torch.equal(dest[k], ref[k]), k
+    ops.mil_step(w, dest, 1.0, x, sex, label, site, 0.75, 0.25, drop, seed)       # accumulate on top
+    for k in ops.STEP_SLOTS:
+        assert (dest[k] - 2 * ref[k]).abs().max().item() <= 1e-6 * max(ref[k].abs().max().item(), 1.0), k
+
+
+def test_flat_adam_matches_torch_adam(cuda):
+    """toad_adam_step_f32 == torch.optim.Adam(lr, weight_decay) (the reference's get_optim, utils/utils.py:63-70)."""
+    from toad_amd.optim import FlatAdam
+    torch.manual_seed(3)
+    n = 1192768
+    p0 = torch.randn(n); grads = [torch.randn(n) * 0.01 for _ in range(5)]
+    ref_p = torch.nn.Parameter(p0.clone())
+    ref = torch.optim.Adam([ref_p], lr=1e-3, weight_decay=1e-5)
+    mine_p = p0.clone().to(cuda)
+    mine = FlatAdam(mine_p, lr=1e-3, weight_decay=1e-5)
+    for g in grads:
+        ref_p.grad = g.clone(); ref.step()
+        mine.step(g.to(cuda))
+    assert (mine_p.cpu() - ref_p.detach()).abs().max().item() <= 2e-6

@@ -466,8 +466,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f32_big_kernel(
     }
 }
 
-// Remainder tiles: C tile = epilogue(sum of the g K-slice slabs), fixed order. grid = (16, 31, 8):
-// x = 16-row strip group of the tile, y = remainder tile index of the XCD, z = XCD.
+// Remainder tiles: C tile = epilogue(sum of the g K-slice slabs), fixed order. grid = (64, 31, 8):
+// x = 4-row strip of the tile (256 threads = 4 rows x 64 float4 columns: one float4 per thread, so a
+// small-bag fix-up still spreads over 64 blocks per tile), y = remainder tile index of the XCD, z = XCD.
 __global__ __launch_bounds__(256) void nt_fixup_kernel(const float *__restrict__ slabs, float *C, int64_t ldc, int M, int N,
                                                         int K, const float *__restrict__ bias, EpiScalars es, const float *addend,
                                                         const float *__restrict__ mask_src, int tiles_m, int tiles_n) {
@@ -476,23 +477,18 @@ __global__ __launch_bounds__(256) void nt_fixup_kernel(const float *__restrict__
     if (tr >= pl.rem || pl.g == 0) return;
     const int q = pl.rounds * PB_BLOCKS_PER_XCD + tr;
     const int m0 = ((q / tiles_n) * kNumXCD + xcd) * PB, n0 = (q % tiles_n) * PB;
-    const int c4 = threadIdx.x & 63, r0 = blockIdx.x * 16 + (threadIdx.x >> 6) * 4;
+    const int c4 = threadIdx.x & 63, lrow = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int col = n0 + c4 * 4;
-    if (col >= N) return;
+    if (col >= N || m0 + lrow >= M) return;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = ld4(bias + col);
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int lrow = r0 + rr;
-        if (m0 + lrow >= M) continue;
-        // slab of K-slice p was written by block (xcd + 8*(tr*g + p))
-        f32x4 v = ld4(slabs + ((int64_t)(xcd + kNumXCD * (tr * pl.g)) * PB + lrow) * PB + c4 * 4);
-        for (int p = 1; p < pl.g; ++p)
-            v += ld4(slabs + ((int64_t)(xcd + kNumXCD * (tr * pl.g + p)) * PB + lrow) * PB + c4 * 4);
-        const int64_t off = (int64_t)(m0 + lrow) * ldc + col;
-        st4(C + off, apply_epilogue(v, es, addend ? addend + off : nullptr, mask_src ? mask_src + off : nullptr, bv,
-                                    (uint64_t)(m0 + lrow) * (uint64_t)N + (uint64_t)col));
-    }
+    // slab of K-slice p was written by block (xcd + 8*(tr*g + p))
+    const float *sp = slabs + ((int64_t)(xcd + kNumXCD * (tr * pl.g)) * PB + lrow) * PB + c4 * 4;
+    f32x4 v = ld4(sp);
+    for (int p = 1; p < pl.g; ++p) v += ld4(sp + (int64_t)p * kNumXCD * PB * PB);
+    const int64_t off = (int64_t)(m0 + lrow) * ldc + col;
+    st4(C + off, apply_epilogue(v, es, addend ? addend + off : nullptr, mask_src ? mask_src + off : nullptr, bv,
+                                (uint64_t)(m0 + lrow) * (uint64_t)N + (uint64_t)col));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -658,7 +654,7 @@ static TnPlan tn_plan(int64_t M, int64_t I, int64_t J) {
     p.tiles = p.ti * p.tj;
     int spx = PB_BLOCKS_PER_XCD / p.tiles;                       // one item per block where possible
     if (spx < 1) spx = 1;
-    const int64_t max_splits = (M + 127) / 128;                 // >= 4 stages per split
+    const int64_t max_splits = M >= 8192 ? (M + 127) / 128 : (M + 31) / 32;   // >= 4 stages per split (>= 1 for short bags)
     while (spx > 1 && (int64_t)spx * kNumXCD > max_splits) --spx;
     int ns = spx * kNumXCD;
     if (ns > max_splits) ns = (int)(max_splits < 1 ? 1 : max_splits);
@@ -906,7 +902,7 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
         bool any_rem = false;
         for (int x = 0; x < kNumXCD; ++x) any_rem |= nt_plan(x, tiles_m, tiles_n, (int)(K / BK)).rem > 0;
         if (any_rem) {
-            hipLaunchKernelGGL(nt_fixup_kernel, dim3(16, PB_BLOCKS_PER_XCD - 1, kNumXCD), dim3(256), 0, st, (const float *)ws, C,
+            hipLaunchKernelGGL(nt_fixup_kernel, dim3(64, PB_BLOCKS_PER_XCD - 1, kNumXCD), dim3(256), 0, st, (const float *)ws, C,
                                ldc, (int)M, (int)N, (int)K, bias, es, addend, mask_src, tiles_m, tiles_n);
             rc = check_launch(what);
         }
@@ -996,7 +992,7 @@ static bool tn_big_ok(int64_t M, int64_t N, int64_t K) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f32_big_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM);
     }
-    return use_big && M >= 128 && N >= 4 && K >= 4;
+    return use_big && M >= 64 && N >= 4 && K >= 4;
 }
 
 extern "C" size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K) {

@@ -123,9 +123,42 @@ __global__ __launch_bounds__(64) void mtl_ce_kernel(const float *logits, const f
     }
 }
 
+// Adam over one flat buffer, same update as torch.optim.Adam (L2 weight decay folded into the gradient;
+// utils/utils.py:63-70 get_optim: Adam(lr, weight_decay=reg)). One launch for all 1.19 M parameters.
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                    float *__restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2_sqrt) {
+    const int64_t n4 = n >> 2;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        f32x4 pp = ld4(p + 4 * e), gg = ld4(g + 4 * e), mm = ld4(m + 4 * e), vv = ld4(v + 4 * e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] + wd * pp[k];
+            mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+            vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+            const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+            pp[k] -= (lr / bc1) * (mm[k] / denom);
+        }
+        st4(p + 4 * e, pp); st4(m + 4 * e, mm); st4(v + 4 * e, vv);
+    }
+}
+
 }  // namespace toad
 
 using namespace toad;
+
+extern "C" int toad_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
+                                   float beta2, float eps, float weight_decay, int64_t step, void *stream) {
+    const char *what = "toad_adam_step_f32";
+    if (!p || !g || !m || !v || n <= 0 || step < 1) { set_error("%s: bad argument", what); return TOAD_EINVAL; }
+    if (n % 4 != 0 || !aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) { set_error("%s: n must be a multiple of 4 and pointers 16-byte aligned", what); return TOAD_EALIGN; }
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    int grid = (int)((n / 4 + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)sqrt(bc2));
+    return check_launch(what);
+}
 
 extern "C" int toad_heads_fwd_f32(const float *M, const float *sex, const float *Wcls, const float *bcls,
                                    const float *Wsite, const float *bsite, float *Mcat, float *logits, float *Y_prob,

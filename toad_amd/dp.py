@@ -47,12 +47,13 @@ def hip_slide_grad(model, grads: Dict[str, torch.Tensor], slide: Slide, beta: fl
     HIP kernels: grads = beta*grads + scale * d(loss)/d(params). ``scale`` (1/global_slides) is folded
     into the CE weights, so no separate gradient-scaling kernel runs. Returns the device loss vector
     [3] = (scale*loss, cls CE, site CE)."""
-    from . import functional as F_, ops
+    from . import ops
+    from .model_toad import _draw_dropout
     bag, sex, label, site = slide
     w = {k: v.detach() for k, v in model._weights().items()}
-    outs, saved = F_.mil_forward(w, bag, sex.to(torch.float32).reshape(1))
-    loss, dl, ds = ops.mtl_ce_fwd_bwd(outs["logits"], outs["site_logits"], label, site, w_cls * scale, w_site * scale)
-    F_.mil_backward(w, saved, dl, ds, grads=grads, beta=beta)
+    drop_p, seed = _draw_dropout(model._dropout and model.training)
+    loss, _, _ = ops.mil_step(w, grads, beta, bag, sex.to(torch.float32).reshape(1), label, site,
+                              w_cls * scale, w_site * scale, drop_p, seed)      # one C-ABI call per slide
     return loss
 
 
@@ -83,7 +84,15 @@ class SlideShardedDP:
         # zero), so the update is a single elementwise launch instead of a 14-tensor multi-tensor apply
         self.flat_param = torch.nn.Parameter(self.flat, requires_grad=True)
         self.flat_param.grad = self.flat_grad
-        self.optimizer = optimizer_factory([self.flat_param])
+        # optimizer_factory == "adam" (or a dict of FlatAdam kwargs) selects the one-launch HIP Adam;
+        # a callable receives [flat_param] and may return any torch optimiser.
+        if optimizer_factory == "adam" or isinstance(optimizer_factory, dict):
+            from .optim import FlatAdam
+            self._flat_adam = FlatAdam(self.flat, **(optimizer_factory if isinstance(optimizer_factory, dict) else {}))
+            self.optimizer = None
+        else:
+            self._flat_adam = None
+            self.optimizer = optimizer_factory([self.flat_param])
         self.slide_grad_fn = slide_grad_fn or hip_slide_grad
 
     def zero_grad(self):
@@ -109,5 +118,8 @@ class SlideShardedDP:
         are this rank's share. Returns the per-slide device loss vectors (no host sync)."""
         losses = self.accumulate(slides, global_slides)
         self.reduce()
-        self.optimizer.step()
+        if self._flat_adam is not None:
+            self._flat_adam.step(self.flat_grad)
+        else:
+            self.optimizer.step()
         return losses

@@ -268,3 +268,54 @@ def mtl_ce_fwd_bwd(logits, site_logits, label, site, w_cls: float = 0.75, w_site
                                                    float(w_site), _p(loss), _p(dlogits), _p(dsite), c, _stream()),
                "toad_mtl_ce_fwd_bwd_f32")
     return loss, dlogits, dsite
+
+
+# ---- whole per-slide step in one C call (toad_mil_step_f32) -------------------------------------------
+STEP_SLOTS = ("w1", "b1", "w2", "b2", "wab", "bab", "wc", "bc", "wcls", "bcls", "wsite", "bsite")
+_GEMM_EVENT_NAMES = ("gemm_fwd", "gemm_fwd", "gemm_fwd", "gemm_wgrad", "gemm_dgrad", "gemm_wgrad", "gemm_dgrad", "gemm_wgrad")
+
+
+def _ptr_array(tensors):
+    import ctypes
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def mil_step(w, grads, beta: float, bag, sex, label, site, w_cls: float = 0.75, w_site: float = 0.25,
+             drop_p: float = 0.0, seed: int = 0, want_logits: bool = False):
+    """forward + weighted CE + backward for one slide in ONE library call. ``w`` / ``grads`` map the STEP_SLOTS
+    to tensors (grads = beta*grads + gradient). Returns (loss[3], logits [1,C] | None, site_logits [1,2] | None)."""
+    import ctypes
+    _chk(bag, "bag"); _chk(sex, "sex"); _chk(label, "label", dtype=torch.int64); _chk(site, "site", dtype=torch.int64)
+    ws_t = [w[k] for k in STEP_SLOTS]
+    gs_t = [grads[k] for k in STEP_SLOTS]
+    for k, t in zip(STEP_SLOTS, ws_t):
+        _chk(t, k)
+    for k, t in zip(STEP_SLOTS, gs_t):
+        _chk(t, "grad " + k)
+    n = bag.shape[0]
+    c = w["wcls"].shape[0]
+    d = w["wc"].shape[1]
+    if bag.shape[1] != 1024 or w["w1"].shape != (512, 1024) or w["wab"].shape != (2 * d, 512):
+        raise ValueError("mil_step: shapes must be TOAD 'big' (1024 -> 512 -> 2x384|256)")
+    lib = _lib.load()
+    dev = bag.device
+    ws = _ws(lib.toad_mil_step_ws_bytes(n, c, d), dev)
+    loss = torch.empty((3,), dtype=torch.float32, device=dev)
+    logits = torch.empty((1, c), dtype=torch.float32, device=dev) if want_logits else None
+    slog = torch.empty((1, 2), dtype=torch.float32, device=dev) if want_logits else None
+    events = None
+    ev_objs = None
+    if _TIMING is not None:
+        ev_objs = [torch.cuda.Event(enable_timing=True) for _ in range(18)]
+        for e in ev_objs:
+            e.record()                     # materialises the underlying hipEvent_t
+        events = (ctypes.c_void_p * 18)(*[e.cuda_event for e in ev_objs])
+    _lib.check(lib.toad_mil_step_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag), _p(sex), _p(label), _p(site),
+                                     float(w_cls), float(w_site), n, c, d, float(drop_p), int(seed), _p(loss), _p(logits),
+                                     _p(slog), _p(ws), ws.numel(), events, _stream()), "toad_mil_step_f32")
+    if ev_objs is not None:
+        _TIMING.setdefault("pool_fwd", []).append((ev_objs[0], ev_objs[1]))
+        for i, name in enumerate(_GEMM_EVENT_NAMES):
+            _TIMING.setdefault(name, []).append((ev_objs[2 + 2 * i], ev_objs[3 + 2 * i]))
+    return loss, logits, slog
