@@ -59,5 +59,13 @@ __device__ __forceinline__ float drop_keep(uint64_t idx, const DropArgs &d) {   
 
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+// streaming store: the line is not kept dirty in L2 for the next kernel to flush (GEMM outputs are consumed by the NEXT launch)
+__device__ __forceinline__ void st4s(float *p, f32x4 v) {
+#ifdef TOAD_PLAIN_STORES
+    st4(p, v);
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
+#endif
+}
 
 }  // namespace toad

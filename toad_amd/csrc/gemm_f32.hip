@@ -422,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f32_big_kernel(
                     st4(slab + urow * PB + svoff, v);
                 } else if (cok && (m0 + urow + hi4) < M) {
                     const int64_t uoff = (int64_t)(m0 + urow) * ldc + ucol;            // wave-uniform
-                    st4(C + uoff + voff, apply_epilogue(v, es, addend ? addend + uoff + voff : nullptr,
+                    st4s(C + uoff + voff, apply_epilogue(v, es, addend ? addend + uoff + voff : nullptr,
                                                         mask_src ? mask_src + uoff + voff : nullptr, bv,
                                                         (uint64_t)(m0 + urow + hi4) * (uint64_t)N + (uint64_t)(ucol + li4)));
                 }
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void nt_fixup_kernel(const float *__restrict__
     f32x4 v = ld4(sp);
     for (int p = 1; p < pl.g; ++p) v += ld4(sp + (int64_t)p * kNumXCD * PB * PB);
     const int64_t off = (int64_t)(m0 + lrow) * ldc + col;
-    st4(C + off, apply_epilogue(v, es, addend ? addend + off : nullptr, mask_src ? mask_src + off : nullptr, bv,
+    st4s(C + off, apply_epilogue(v, es, addend ? addend + off : nullptr, mask_src ? mask_src + off : nullptr, bv,
                                 (uint64_t)(m0 + lrow) * (uint64_t)N + (uint64_t)col));
 }
 
