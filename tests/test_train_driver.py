@@ -1,0 +1,76 @@
+"""The train/validate driver: bookkeeping on CPU with a stub model; the real loop on the GPU against the
+oracle stepping the same slides with plain SGD."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import toad_oracle as orc
+
+
+class _Stub(torch.nn.Module):
+    """Returns preset logits per call; has one parameter so loss.backward()/optimizer work (CPU)."""
+
+    def __init__(self, table):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+        self.table, self.i = table, 0
+
+    def forward(self, data, sex):
+        lg, sl = self.table[self.i % len(self.table)]
+        self.i += 1
+        lg = lg + self.w * 0
+        return {"logits": lg, "site_logits": sl + self.w * 0, "Y_prob": torch.softmax(lg, 1), "site_prob": torch.softmax(sl, 1),
+                "Y_hat": lg.argmax(1, keepdim=True), "site_hat": sl.argmax(1, keepdim=True)}
+
+
+def test_bookkeeping_matches_reference_formulas_cpu():
+    from toad_amd.train import train_loop, validate, _auc
+    torch.manual_seed(0)
+    table = [(torch.randn(1, 3), torch.randn(1, 2)) for _ in range(7)]
+    labels = [0, 1, 2, 1, 0, 2, 2]; sites = [0, 1, 1, 0, 0, 1, 0]
+    loader = [(torch.zeros(4, 8), torch.tensor([l]), torch.tensor([s]), torch.tensor([1.0])) for l, s in zip(labels, sites)]
+    m = _Stub(table)
+    r = train_loop(0, m, loader, torch.optim.SGD(m.parameters(), lr=0.0), 3)
+    ce = torch.nn.functional.cross_entropy
+    exp_cls = np.mean([ce(t[0], torch.tensor([l])).item() for t, l in zip(table, labels)])
+    exp_err = np.mean([float(t[0].argmax().item() != l) for t, l in zip(table, labels)])
+    assert abs(r["cls_loss"] - exp_cls) < 1e-6 and abs(r["cls_error"] - exp_err) < 1e-12 and r["slides"] == 7
+    assert sum(c for _, _, c in r["cls_acc"]) == 7 and [c for _, _, c in r["cls_acc"]] == [2, 2, 3]
+    m.i = 0
+    v = validate(m, loader, 3)
+    assert v["prob"].shape == (7, 3) and abs(v["cls_loss"] - exp_cls) < 1e-6
+    from sklearn.metrics import roc_auc_score
+    assert abs(v["site_auc"] - roc_auc_score(sites, v["site_prob"][:, 1])) < 1e-12
+    assert 0.0 <= v["cls_auc"] <= 1.0
+    assert abs(_auc(np.array([0, 1, 1, 0]), np.array([[.9, .1], [.2, .8], [.4, .6], [.7, .3]]), 2) - 1.0) < 1e-12
+
+
+@pytest.mark.gpu
+def test_train_loop_tracks_oracle_sgd(cuda):
+    """6 slides, one SGD step each through the reference call sequence on the HIP kernels; the CPU oracle
+    takes the same steps. Parameters after the epoch agree to 1e-4 (north-star tolerance)."""
+    from toad_amd import TOAD_fc_mtl_concat
+    from toad_amd.train import train_loop, validate
+    torch.manual_seed(8)
+    model = TOAD_fc_mtl_concat(n_classes=18)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.relocate()
+    slides = []
+    for i, n in enumerate((120, 333, 64, 257, 90, 500)):
+        g = torch.Generator().manual_seed(300 + i)
+        slides.append((torch.randn(n, 1024, generator=g), torch.tensor([i % 18]), torch.tensor([i % 2]), torch.tensor([float(i % 2)])))
+    lr = 0.05
+    r = train_loop(0, model, slides, torch.optim.SGD(model.parameters(), lr=lr), 18)
+    for data, label, site, sex in slides:
+        out, loss, grads = orc.fwd_bwd(params, data, sex, label, site)
+        for k in params:
+            params[k] = params[k] - lr * grads[k]
+    new = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    for k in params:
+        assert (new[k] - params[k]).abs().max().item() <= 1e-4, k
+    assert r["slides"] == 6 and 0.0 <= r["cls_error"] <= 1.0 and np.isfinite(r["cls_loss"])
+    v = validate(model, slides, 18)
+    o = [orc.forward(params, d, s)[0] for d, _, _, s in slides]
+    ref_prob = torch.cat([x["Y_prob"] for x in o]).numpy()
+    assert np.abs(v["prob"] - ref_prob).max() <= 1e-4
+    assert v["slides"] == 6

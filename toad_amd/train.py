@@ -1,0 +1,123 @@
+"""Train / validate loops over the drop-in model, mirroring the reference harness.
+
+Reference: ``utils/core_utils_mtl_concat.py`` — ``train_loop`` (:189-259), ``validate`` (:262-366),
+``Accuracy_Logger`` (:13-43), ``calculate_error`` (``utils/utils.py:135-138``). The sequence per slide is
+the reference's (to device, ``model(data, sex)``, ``0.75*CE + 0.25*CE``, ``backward``, ``step``,
+``zero_grad``); what differs is bookkeeping: the reference synchronises the host three times per slide
+(two ``.item()`` at :216-217 and ``int(Y_hat)`` at :24); here the running sums live on the device and are
+read back once per epoch.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+class AccuracyLogger:
+    """Per-class hit / count tallies (reference ``Accuracy_Logger``), kept on the device."""
+
+    def __init__(self, n_classes: int, device):
+        self.n_classes = n_classes
+        self.count = torch.zeros(n_classes, dtype=torch.int64, device=device)
+        self.correct = torch.zeros(n_classes, dtype=torch.int64, device=device)
+
+    def log(self, y_hat: torch.Tensor, y: torch.Tensor) -> None:
+        y = y.reshape(-1).to(torch.int64)
+        hit = (y_hat.reshape(-1).to(torch.int64) == y).to(torch.int64)
+        self.count.index_add_(0, y, torch.ones_like(y))
+        self.correct.index_add_(0, y, hit)
+
+    def summary(self):
+        """[(acc or None, correct, count)] per class — ``get_summary`` of the reference."""
+        c, n = self.correct.cpu().tolist(), self.count.cpu().tolist()
+        return [((ci / ni) if ni else None, ci, ni) for ci, ni in zip(c, n)]
+
+
+def _to_device(batch, device):
+    data, label, site, sex = batch
+    return (data.to(device, non_blocking=True), label.to(device, non_blocking=True),
+            site.to(device, non_blocking=True), sex.float().to(device, non_blocking=True))
+
+
+def train_loop(epoch: int, model, loader: Iterable, optimizer, n_classes: int, loss_fn=None) -> Dict[str, object]:
+    """One epoch, one optimiser step per slide (the reference's batch size is 1, utils/utils.py:51-55)."""
+    device = next(model.parameters()).device
+    loss_fn = loss_fn or nn.CrossEntropyLoss()
+    model.train()
+    cls_logger, site_logger = AccuracyLogger(n_classes, device), AccuracyLogger(2, device)
+    sums = torch.zeros(4, dtype=torch.float64, device=device)      # cls loss, site loss, cls error, site error
+    n = 0
+    for batch in loader:
+        data, label, site, sex = _to_device(batch, device)
+        res = model(data, sex)
+        cls_loss = loss_fn(res["logits"], label)
+        site_loss = loss_fn(res["site_logits"], site)
+        loss = cls_loss * 0.75 + site_loss * 0.25                     # core_utils:213-215
+        cls_logger.log(res["Y_hat"], label)
+        site_logger.log(res["site_hat"], site)
+        with torch.no_grad():
+            sums += torch.stack([cls_loss.detach().double(), site_loss.detach().double(),
+                                 (res["Y_hat"].reshape(-1) != label.reshape(-1)).double().mean(),   # calculate_error
+                                 (res["site_hat"].reshape(-1) != site.reshape(-1)).double().mean()])
+        loss.backward()
+        optimizer.step()
+        optimizer.zero_grad()
+        n += 1
+    s = (sums / max(n, 1)).cpu().tolist()                             # the epoch's only host sync
+    return {"epoch": epoch, "slides": n, "cls_loss": s[0], "site_loss": s[1], "cls_error": s[2], "site_error": s[3],
+            "cls_acc": cls_logger.summary(), "site_acc": site_logger.summary()}
+
+
+def _auc(labels: np.ndarray, probs: np.ndarray, n_classes: int) -> float:
+    """core_utils:311-330: binary -> AUC of class 1; multi-class -> mean one-vs-rest AUC over classes present."""
+    from sklearn.metrics import auc as calc_auc, roc_auc_score, roc_curve
+    from sklearn.preprocessing import label_binarize
+    if n_classes == 2:
+        return float(roc_auc_score(labels, probs[:, 1]))
+    binary = label_binarize(labels, classes=list(range(n_classes)))
+    aucs = []
+    for c in range(n_classes):
+        if c in labels:
+            fpr, tpr, _ = roc_curve(binary[:, c], probs[:, c])
+            aucs.append(calc_auc(fpr, tpr))
+        else:
+            aucs.append(float("nan"))
+    return float(np.nanmean(np.array(aucs)))
+
+
+@torch.no_grad()
+def validate(model, loader: Iterable, n_classes: int, loss_fn=None, with_auc: bool = True) -> Dict[str, object]:
+    """Forward-only pass (reference ``validate`` / ``summary``): losses, errors, per-slide probabilities, AUCs."""
+    device = next(model.parameters()).device
+    loss_fn = loss_fn or nn.CrossEntropyLoss()
+    model.eval()
+    cls_logger, site_logger = AccuracyLogger(n_classes, device), AccuracyLogger(2, device)
+    sums = torch.zeros(4, dtype=torch.float64, device=device)
+    probs, site_probs, labels, sites = [], [], [], []
+    n = 0
+    for batch in loader:
+        data, label, site, sex = _to_device(batch, device)
+        res = model(data, sex)
+        cls_logger.log(res["Y_hat"], label)
+        site_logger.log(res["site_hat"], site)
+        sums += torch.stack([loss_fn(res["logits"], label).double(), loss_fn(res["site_logits"], site).double(),
+                             (res["Y_hat"].reshape(-1) != label.reshape(-1)).double().mean(),
+                             (res["site_hat"].reshape(-1) != site.reshape(-1)).double().mean()])
+        probs.append(res["Y_prob"]); site_probs.append(res["site_prob"]); labels.append(label); sites.append(site)
+        n += 1
+    s = (sums / max(n, 1)).cpu().tolist()
+    out = {"slides": n, "cls_loss": s[0], "site_loss": s[1], "cls_error": s[2], "site_error": s[3],
+           "cls_acc": cls_logger.summary(), "site_acc": site_logger.summary()}
+    if n:
+        out["prob"] = torch.cat(probs).cpu().numpy(); out["site_prob"] = torch.cat(site_probs).cpu().numpy()
+        out["labels"] = torch.cat(labels).reshape(-1).cpu().numpy(); out["sites"] = torch.cat(sites).reshape(-1).cpu().numpy()
+        if with_auc:
+            try:
+                out["cls_auc"] = _auc(out["labels"], out["prob"], n_classes)
+                out["site_auc"] = _auc(out["sites"], out["site_prob"], 2)
+            except Exception as e:                                   # e.g. a single class present
+                out["auc_error"] = repr(e)
+    return out
