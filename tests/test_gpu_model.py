@@ -321,3 +321,26 @@ def test_flat_adam_matches_torch_adam(cuda):
         ref_p.grad = g.clone(); ref.step()
         mine.step(g.to(cuda))
     assert (mine_p.cpu() - ref_p.detach()).abs().max().item() <= 2e-6
+
+
+def test_size_arg_small_end_to_end(cuda):
+    """size_arg="small" ([1024, 512, 256], models/model_toad.py:56): forward, loss, backward vs the oracle."""
+    from toad_amd import TOAD_fc_mtl_concat
+    torch.manual_seed(12)
+    model = TOAD_fc_mtl_concat(size_arg="small", n_classes=5)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.05)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    assert params["attention_net.4.attention_a.0.weight"].shape == (256, 512)
+    model.relocate()
+    x = torch.randn(2111, 1024); sex = torch.tensor([0.0]); label = torch.tensor([4]); site = torch.tensor([1])
+    res = model(x.to(cuda), sex.to(cuda))
+    loss = orc.loss_fn(res["logits"], label.to(cuda), res["site_logits"], site.to(cuda))
+    loss.backward()
+    o_out, o_loss, o_grads = orc.fwd_bwd(params, x, sex, label, site)
+    for k in ("logits", "site_logits", "A"):
+        assert (res[k].detach().cpu() - o_out[k]).abs().max().item() <= 1e-4, k
+    for k, p in model.named_parameters():
+        assert (p.grad.cpu() - o_grads[k]).abs().max().item() <= 1e-4, k
