@@ -492,6 +492,282 @@ __global__ __launch_bounds__(256) void nt_fixup_kernel(const float *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// NT, persistent 256x256, SPLIT-bf16 arithmetic (fp32-equivalent results on the bf16 matrix pipe)
+//
+// x = h + m + l with three bf16 (24 significand bits); a product keeps the six terms
+// hh + hm + mh + mm + hl + lh (dropped: <= 2^-24 relative), accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16. Measured (tools/ubench/bf16x3_probe.hip): max error 4.85e-6 vs 4.68e-6 for
+// the exact-fp32 MFMA chain at K = 1024 - indistinguishable - at 1/2.67 of the matrix-pipe time.
+//  * A (activations, fp32 in HBM): staged by LDS-DMA exactly like gemm_nt_f32_big_kernel and split in
+//    registers when its fragments are read: 16 floats per lane per 16-deep step, ~5.5 VALU ops each,
+//    i.e. ~88 VALU against 48 MFMAs - hidden in the MFMA shadow.
+//  * B (weights): pre-split ONCE per call by split_planes_kernel into three bf16 planes already in the
+//    LDS stage order (column-interleaved positions, 16-B chunks XOR-swizzled with (pos >> 2) & 3), so its
+//    LDS-DMA is a linear copy and its fragments are single conflict-free ds_read_b128's (8 bf16).
+//  * stage = 32 k: A 32 KB + 3 x 16 KB planes = 80 KB; two stages = the whole 160 KB LDS of the CU.
+//    A stage is consumed as 8 units (2 k16 steps x 4 column sub-tiles) of 12 MFMAs; B planes are read one
+//    unit ahead, A one k16 step ahead, the stage barrier sits before the last unit.
+// Work decomposition, epilogue, K-split tail and fix-up are those of gemm_nt_f32_big_kernel.
+// ------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int SP_A_BYTES = PB * BK * 4;                         // 32,768
+constexpr int SP_PLANE_BYTES = PB * BK * 2;                     // 16,384
+constexpr int SP_STAGE_BYTES = SP_A_BYTES + 3 * SP_PLANE_BYTES; // 81,920
+constexpr int SP_SMEM = 2 * SP_STAGE_BYTES;                     // 163,840 = all of LDS
+
+// bits of x reduced to bf16, low 16 bits cleared. Default: truncation (1 VALU op). Measured against fp64 on
+// GEMM outputs and on all 14 gradients (tools/gemm_accuracy.py, tools/grad_errors.py): truncation and
+// round-to-nearest (-DTOAD_SPLIT_RN, 3 ops) are equally accurate - both at the exact-fp32 kernel's error level -
+// because three 8-bit pieces hold all 24 significand bits either way; RN costs ~10 % of the kernel's speed.
+__device__ __forceinline__ unsigned bf16_rn(unsigned u) {
+#ifdef TOAD_SPLIT_RN
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+#else
+    return u & 0xFFFF0000u;
+#endif
+}
+// Bp[tile][kstage][plane][pos 0..255][phys chunk 0..3][8 bf16]  <-  B[n, k] = src[n * sn + k * sk]
+__global__ __launch_bounds__(256) void split_planes_kernel(const float *__restrict__ src, int64_t sn, int64_t sk,
+                                                            unsigned short *__restrict__ Bp, int N, int K, int tiles_n) {
+    const int nk = K / BK;
+    const int64_t total = (int64_t)tiles_n * nk * PB * 4;                 // one thread per (tile, stage, pos, logical chunk)
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int chunk = (int)(t & 3), pos = (int)((t >> 2) & (PB - 1));
+        const int64_t ts = t >> 10;                                       // tile * nk + stage
+        const int stage = (int)(ts % nk), tile = (int)(ts / nk);
+        const int pp = pos & 127;
+        const int col = tile * PB + (pos & 128) + 4 * (pp & 31) + (pp >> 5);
+        const int phys = chunk ^ ((pos >> 2) & 3);
+        unsigned short h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = stage * BK + chunk * 8 + e;
+            const float x = col < N ? src[(int64_t)col * sn + (int64_t)k * sk] : 0.f;
+            const unsigned hb = bf16_rn(__builtin_bit_cast(unsigned, x));
+            const float r1 = x - __builtin_bit_cast(float, hb);
+            const unsigned mb = bf16_rn(__builtin_bit_cast(unsigned, r1));
+            const float r2 = r1 - __builtin_bit_cast(float, mb);
+            h[e] = (unsigned short)(hb >> 16); m[e] = (unsigned short)(mb >> 16);
+            l[e] = (unsigned short)(bf16_rn(__builtin_bit_cast(unsigned, r2)) >> 16);
+        }
+        unsigned short *dst = Bp + ts * (3 * PB * BK) + pos * BK + phys * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dst[e] = h[e]; dst[PB * BK + e] = m[e]; dst[2 * PB * BK + e] = l[e]; }
+    }
+}
+
+// split 8 fp32 into three bf16x8 planes h, m, l with x = h + m + l (+ < 2^-24 |x|): every residual x - h,
+// (x - h) - m is exact in fp32.
+__device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+    unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? x0[e] : x1[e - 4];
+        hh[e] = bf16_rn(__builtin_bit_cast(unsigned, x));
+        const float r1 = x - __builtin_bit_cast(float, hh[e]);
+        mm[e] = bf16_rn(__builtin_bit_cast(unsigned, r1));
+        const float r2 = r1 - __builtin_bit_cast(float, mm[e]);
+        ll[e] = bf16_rn(__builtin_bit_cast(unsigned, r2));
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 hp, mp, lp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {      // dword e = bf16 of element 2e (low half) | bf16 of element 2e+1 (high half)
+        hp[e] = __builtin_amdgcn_perm(hh[2 * e + 1], hh[2 * e], 0x07060302u);
+        mp[e] = __builtin_amdgcn_perm(mm[2 * e + 1], mm[2 * e], 0x07060302u);
+        lp[e] = __builtin_amdgcn_perm(ll[2 * e + 1], ll[2 * e], 0x07060302u);
+    }
+    h = __builtin_bit_cast(bf16x8, hp); m = __builtin_bit_cast(bf16x8, mp); l = __builtin_bit_cast(bf16x8, lp);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_split_big_kernel(
+    const float *__restrict__ A, int64_t lda, const unsigned short *__restrict__ Bp,
+    float *C, int64_t ldc, int M, int N, int K, const float *__restrict__ bias, EpiScalars es, const float *addend,
+    const float *__restrict__ mask_src, float *__restrict__ slabs, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, hi = lane >> 5;
+    const int nk = K / BK;
+
+    // ---- work list (identical to gemm_nt_f32_big_kernel)
+    const int xcd = blockIdx.x % kNumXCD, j = blockIdx.x / kNumXCD;
+    const NtPlan pl = nt_plan(xcd, tiles_m, tiles_n, nk);
+    const bool has_part = j < pl.rem * pl.g;
+    const int n_items = pl.rounds + (has_part ? 1 : 0);
+    if (n_items == 0) return;
+    const int part_tile = pl.g ? pl.rounds * PB_BLOCKS_PER_XCD + j / pl.g : 0;
+    const int part = pl.g ? j % pl.g : 0;
+    const int part_k0 = pl.g ? (part * nk) / pl.g : 0, part_k1 = pl.g ? ((part + 1) * nk) / pl.g : 0;
+    auto item_tile = [&](int i) { return i < pl.rounds ? j + i * PB_BLOCKS_PER_XCD : part_tile; };
+    auto item_k0 = [&](int i) { return i < pl.rounds ? 0 : part_k0; };
+    auto item_k1 = [&](int i) { return i < pl.rounds ? nk : part_k1; };
+    const int total = pl.rounds * nk + (has_part ? part_k1 - part_k0 : 0);
+
+    // ---- staging
+    const char *Ab = reinterpret_cast<const char *>(A), *Bpb = reinterpret_cast<const char *>(Bp);
+    const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
+    unsigned aoff[4];
+    const unsigned lane16 = lane * 16u;
+    auto dma1 = [&](const char *sbase, unsigned voff, unsigned lds_byte) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+    };
+    auto set_tile = [&](int q, int &m0, int &n0, int &tn) {
+        m0 = ((q / tiles_n) * kNumXCD + xcd) * PB;
+        tn = q % tiles_n;
+        n0 = tn * PB;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int p = wave * 32 + 8 * jj + (lane >> 3);
+            const int ch = (lane & 7) ^ ((p >> 1) & 7);
+            aoff[jj] = (unsigned)min(m0 + p, M - 1) * (unsigned)(lda * 4) + ch * 16;
+        }
+    };
+    auto dma = [&](int buf, int kt, int tn) {
+        const unsigned dst = lds_base + (unsigned)buf * SP_STAGE_BYTES;
+        const char *ak = Ab + kt * (BK * 4);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) dma1(ak, aoff[jj], dst + (wave * 32 + jj * 8) * (BK * 4));
+        const char *bk = Bpb + (int64_t)(tn * nk + kt) * (3 * SP_PLANE_BYTES) + wave * 6144;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dma1(bk + i * 1024, lane16, dst + SP_A_BYTES + wave * 6144 + i * 1024);
+    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+    // ---- fragment addressing
+    const int swA = (li >> 1) & 7, swB = (li >> 2) & 3;
+    const int aposf = (wm * 64 + li) * BK;                                   // floats, + a*32*BK
+    const int bposb = SP_A_BYTES + (wn * 128 + li) * 64;                     // bytes, + plane*16384 + b*32*64
+    auto read_a = [&](int buf, int s, f32x4 (&f)[2][2]) {                    // raw fp32 of k16 step s: [a][lo/hi 4 floats]
+        const float *base = smem + buf * (SP_STAGE_BYTES / 4) + aposf;
+        const int c0 = ((4 * s + 2 * hi) ^ swA) * 4, c1 = ((4 * s + 2 * hi + 1) ^ swA) * 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { f[a][0] = ld4(base + a * 32 * BK + c0); f[a][1] = ld4(base + a * 32 * BK + c1); }
+    };
+    auto read_b = [&](int buf, int s, int b, bf16x8 (&q)[3]) {
+        const char *base = reinterpret_cast<const char *>(smem) + buf * SP_STAGE_BYTES + bposb + b * 32 * 64 +
+                           ((2 * s + hi) ^ swB) * 16;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) q[p] = *reinterpret_cast<const bf16x8 *>(base + p * SP_PLANE_BYTES);
+    };
+    f32x16 acc[2][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    };
+    bf16x8 ap[2][3], an[2][3];           // split A fragments of the current / next k16 step: [sub-tile a][h, m, l]
+    f32x4 fa[2][2];                      // raw A fragments of the next k16 step
+    bf16x8 bq[3], bn[3];                 // B planes of the current / next unit
+    auto convert_a = [&](bf16x8 (&dst)[2][3]) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) split8(fa[a][0], fa[a][1], dst[a][0], dst[a][1], dst[a][2]);
+    };
+    auto mma12 = [&](int b) {            // six terms, small ones first; the two row sub-tiles alternate
+#define TOAD_T(PA, PB_) \
+        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][PA], bq[PB_], acc[0][b], 0, 0, 0); \
+        acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1][PA], bq[PB_], acc[1][b], 0, 0, 0);
+        TOAD_T(2, 0) TOAD_T(0, 2) TOAD_T(1, 1) TOAD_T(1, 0) TOAD_T(0, 1) TOAD_T(0, 0)
+#undef TOAD_T
+    };
+    // one unit = 12 MFMAs on column sub-tile b with the current planes; the next unit's B planes are fetched first.
+    // `conv`: also split the raw A fragments of the next k16 step into `an` INSIDE this unit's scheduling
+    // region, so the ~180 VALU ops of the conversion issue in the shadow of the 12 MFMAs.
+    auto unit = [&](int b, int nbuf, int ns, int nb, bool fetch, bool conv) {
+        if (fetch) read_b(nbuf, ns, nb, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        mma12(b);
+        if (conv) convert_a(an);
+        __builtin_amdgcn_sched_barrier(0);
+        if (fetch) { bq[0] = bn[0]; bq[1] = bn[1]; bq[2] = bn[2]; }
+        if (conv) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) ap[a][p] = an[a][p];
+        }
+    };
+
+    auto epilogue = [&](int m0, int n0, bool partial) {
+        int li4 = 4 * li, hi4 = 4 * hi;
+        asm volatile("" : "+v"(li4), "+v"(hi4));
+        const int voff = hi4 * (int)ldc + li4;
+        const int svoff = hi4 * PB + li4;
+        const int ucol = n0 + wn * 128;
+        const bool cok = (ucol + li4) < N;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias && cok) bv = ld4(bias + ucol + li4);
+        asm volatile("" : "+v"(bv));
+        float *slab = slabs + (int64_t)blockIdx.x * PB * PB + wn * 128;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int urow = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2);
+                f32x4 v = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+                if (partial) {
+                    st4(slab + urow * PB + svoff, v);
+                } else if (cok && (m0 + urow + hi4) < M) {
+                    const int64_t uoff = (int64_t)(m0 + urow) * ldc + ucol;
+                    st4s(C + uoff + voff, apply_epilogue(v, es, addend ? addend + uoff + voff : nullptr,
+                                                         mask_src ? mask_src + uoff + voff : nullptr, bv,
+                                                         (uint64_t)(m0 + urow + hi4) * (uint64_t)N + (uint64_t)(ucol + li4)));
+                }
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    int it = 0, kt = item_k0(0), kend = item_k1(0);
+    int nit = 0, nkt = kt, nkend = kend;
+    int cur_m0, cur_n0, cur_tn, nxt_m0, nxt_n0, nxt_tn;
+    set_tile(item_tile(0), cur_m0, cur_n0, cur_tn);
+    nxt_m0 = cur_m0; nxt_n0 = cur_n0; nxt_tn = cur_tn;
+    dma(0, kt, cur_tn);
+    zero_acc();
+    dma_wait();
+    __syncthreads();
+    read_a(0, 0, fa);
+    read_b(0, 0, 0, bq);
+    convert_a(ap);
+    for (int step = 0; step < total; ++step) {
+        const int buf = step & 1;
+        const bool more = (step + 1) < total;
+        if (more) {
+            if (++nkt == nkend) { ++nit; nkt = item_k0(nit); nkend = item_k1(nit); set_tile(item_tile(nit), nxt_m0, nxt_n0, nxt_tn); }
+            dma(buf ^ 1, nkt, nxt_tn);
+        }
+        // k16 step 0: units 0..3 (raw A of step 1 is fetched up front and split during unit 3)
+        read_a(buf, 1, fa);
+        unit(0, buf, 0, 1, true, false);
+        unit(1, buf, 0, 2, true, false);
+        unit(2, buf, 0, 3, true, false);
+        unit(3, buf, 1, 0, true, true);
+        // k16 step 1: units 4..7
+        unit(0, buf, 1, 1, true, false);
+        unit(1, buf, 1, 2, true, false);
+        unit(2, buf, 1, 3, true, false);
+        dma_wait();
+        __syncthreads();                    // next stage landed everywhere; this stage is fully read
+        if (more) read_a(buf ^ 1, 0, fa);
+        unit(3, buf ^ 1, 0, 0, more, more);
+        if (++kt == kend) {
+            epilogue(cur_m0, cur_n0, it >= pl.rounds);
+            zero_acc();
+            ++it;
+            kt = item_k0(it); kend = item_k1(it);
+            cur_m0 = nxt_m0; cur_n0 = nxt_n0; cur_tn = nxt_tn;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // TN (wgrad): slab[s][I,J] = sum_{m in split s} A[m,I] B[m,J];  colsum slab[s][I] = sum_m A[m,I]
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(
@@ -892,6 +1168,36 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_f32_big_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM);
     }
+    static int use_split = -1;
+    if (use_split < 0) {
+        const char *e = getenv("TOAD_GEMM_SPLIT");         // A/B knob
+        use_split = e ? atoi(e) : 1;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_split_big_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SP_SMEM);
+    }
+    if (use_big && use_split && ws && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && (uint64_t)M * lda * 4 < (1ull << 32)) {
+        // B is given as B[n, k] = Bsrc[n * bsn + k * bsk]; split it into pre-swizzled bf16 planes behind the slabs
+        const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
+        unsigned short *planes = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(ws) + (size_t)PB_GRID * PB * PB * sizeof(float));
+        const int64_t pthreads = (int64_t)tiles_n * (K / BK) * PB * 4;
+        int pgrid = (int)((pthreads + 255) / 256);
+        if (pgrid > 4096) pgrid = 4096;
+        hipLaunchKernelGGL(split_planes_kernel, dim3(pgrid), dim3(256), 0, st, B, ldb, (int64_t)1, planes, (int)N, (int)K, tiles_n);
+        int rc = check_launch(what);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gemm_nt_split_big_kernel, dim3(PB_GRID), dim3(512), SP_SMEM, st, A, lda, planes, C, ldc, (int)M,
+                           (int)N, (int)K, bias, es, addend, mask_src, (float *)ws, tiles_m, tiles_n);
+        rc = check_launch(what);
+        if (rc) return rc;
+        bool any_rem = false;
+        for (int x = 0; x < kNumXCD; ++x) any_rem |= nt_plan(x, tiles_m, tiles_n, (int)(K / BK)).rem > 0;
+        if (any_rem) {
+            hipLaunchKernelGGL(nt_fixup_kernel, dim3(64, PB_BLOCKS_PER_XCD - 1, kNumXCD), dim3(256), 0, st, (const float *)ws, C,
+                               ldc, (int)M, (int)N, (int)K, bias, es, addend, mask_src, tiles_m, tiles_n);
+            rc = check_launch(what);
+        }
+        return rc;
+    }
     if (use_big && ws && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && (uint64_t)M * lda * 4 < (1ull << 32) &&
         (uint64_t)N * ldb * 4 < (1ull << 32)) {
         const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
@@ -951,8 +1257,10 @@ static WgradPlan wgrad_plan(int64_t M, int64_t N, int64_t K) {
 using namespace toad;
 
 extern "C" size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K) {
-    (void)M; (void)N; (void)K;
-    return (size_t)PB_GRID * PB * PB * sizeof(float);     // one 256x256 fp32 slab per persistent block (64 MiB)
+    (void)M;
+    // one 256x256 fp32 slab per persistent block (64 MiB) + the three bf16 planes of the weight operand
+    const size_t tiles_n = (size_t)((N + PB - 1) / PB), kpad = (size_t)((K + BK - 1) / BK * BK);
+    return (size_t)PB_GRID * PB * PB * sizeof(float) + tiles_n * PB * kpad * 6 + 256;
 }
 
 static int check_ws(void *ws, size_t ws_bytes, int64_t M, int64_t N, int64_t K, const char *what) {

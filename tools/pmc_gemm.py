@@ -11,4 +11,5 @@ dp = rn(N, 768); dh = rn(N, 512); h = rn(N, 512); wabt = rn(512, 768)
 for _ in range(3):
     ops.linear_act_fwd(x, w1, b1, 1)
     ops.linear_dgrad(dp, wabt, dh, h)
+    ops.linear_wgrad(dh, x)
 torch.cuda.synchronize()
