@@ -1114,6 +1114,214 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_f32_big_kernel(
     (void)cur_mend;
 }
 
+// ------------------------------------------------------------------------------------------
+// TN, persistent 256x256, SPLIT-bf16 arithmetic (wgrad on the bf16 matrix pipe)
+//
+// Same work decomposition, staging (fp32 rows by LDS-DMA), ragged-tail zeroing, slabs and column sums as
+// gemm_tn_f32_big_kernel; the product is computed like gemm_nt_split_big_kernel (x = h+m+l, six terms).
+// Both operands are activations here, so both are split in registers. The reduction runs over image ROWS:
+// for a 16-deep MFMA step lane (li, hi) gathers rows 16s+8hi .. +7 of its columns - 8 ds_read_b64 for
+// the two A sub-tiles and 8 ds_read_b128 for the four B sub-tiles (conflict-free as in the fp32 kernel) -
+// and packs each sub-tile's 8 row values into three bf16x8 planes. 48 floats are split per lane per step
+// (~5.5 VALU ops each) against 48 MFMAs; the second wave of the SIMD computes while this one gathers.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8s(const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+    unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hh[e] = bf16_rn(__builtin_bit_cast(unsigned, x[e]));
+        const float r1 = x[e] - __builtin_bit_cast(float, hh[e]);
+        mm[e] = bf16_rn(__builtin_bit_cast(unsigned, r1));
+        const float r2 = r1 - __builtin_bit_cast(float, mm[e]);
+        ll[e] = bf16_rn(__builtin_bit_cast(unsigned, r2));
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 hp, mp, lp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hp[e] = __builtin_amdgcn_perm(hh[2 * e + 1], hh[2 * e], 0x07060302u);
+        mp[e] = __builtin_amdgcn_perm(mm[2 * e + 1], mm[2 * e], 0x07060302u);
+        lp[e] = __builtin_amdgcn_perm(ll[2 * e + 1], ll[2 * e], 0x07060302u);
+    }
+    h = __builtin_bit_cast(bf16x8, hp); m = __builtin_bit_cast(bf16x8, mp); l = __builtin_bit_cast(bf16x8, lp);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_split_big_kernel(
+    const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
+    float *__restrict__ slab, float *__restrict__ colsum_slab, int Mred, int I, int J, int rows_per_split,
+    int ti, int tj, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int li = lane & 31, hi = lane >> 5;
+    const int tiles = ti * tj;
+
+    const int xcd = blockIdx.x % kNumXCD, jb = blockIdx.x / kNumXCD;
+    const int splits_x = (nsplit - xcd + kNumXCD - 1) / kNumXCD;
+    const int items_x = splits_x * tiles;
+    const int n_items = jb < items_x ? (items_x - jb + PB_BLOCKS_PER_XCD - 1) / PB_BLOCKS_PER_XCD : 0;
+    if (n_items == 0) return;
+    auto item_split = [&](int i) { return ((jb + i * PB_BLOCKS_PER_XCD) / tiles) * kNumXCD + xcd; };
+    auto item_tile = [&](int i) { return (jb + i * PB_BLOCKS_PER_XCD) % tiles; };
+    auto split_steps = [&](int sp) {
+        const int mb = sp * rows_per_split, me = min(Mred, mb + rows_per_split);
+        return (me - mb + BK - 1) / BK;
+    };
+    int total = 0;
+    for (int i = 0; i < n_items; ++i) total += split_steps(item_split(i));
+
+    const char *Ab = reinterpret_cast<const char *>(A), *Bb = reinterpret_cast<const char *>(B);
+    const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
+    auto dma1 = [&](const char *sbase, unsigned voff, unsigned lds_byte) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+    };
+    unsigned avoff = 0, bvoff = 0;
+    int st_i0 = 0, st_j0 = 0, st_mend = 0;
+    auto set_item = [&](int i, int &mrow) {
+        const int sp = item_split(i), tl = item_tile(i);
+        st_i0 = (tl / tj) * PB; st_j0 = (tl % tj) * PB;
+        mrow = sp * rows_per_split;
+        st_mend = min(Mred, mrow + rows_per_split);
+        avoff = (unsigned)min(st_i0 + 4 * lane, I - 4) * 4u;
+        bvoff = (unsigned)min(st_j0 + 4 * lane, J - 4) * 4u;
+    };
+    auto dma = [&](int buf, int m) {
+        const unsigned dst = lds_base + (unsigned)(buf * 2 * PB_TILE + wave * 4 * PB) * 4u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = min(m + wave * 4 + r, Mred - 1);
+            dma1(Ab + (int64_t)row * (lda * 4), avoff, dst + r * PB * 4);
+            dma1(Bb + (int64_t)row * (ldb * 4), bvoff, dst + (PB_TILE + r * PB) * 4);
+        }
+    };
+    auto zero_tail = [&](int buf, int m, int mend) {
+        if (m + 32 <= mend) return;
+        float *img = smem + buf * 2 * PB_TILE + wave * 4 * PB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (m + wave * 4 + r >= mend) {
+                st4(img + r * PB + 4 * lane, f32x4{0.f, 0.f, 0.f, 0.f});
+                st4(img + PB_TILE + r * PB + 4 * lane, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+        }
+    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+    // ---- fragments of one 16-deep step: rows 16s + 8hi + j (j = 0..7) of this lane's columns
+    const int aoffs = 8 * hi * PB + wi * 64 + 2 * li, boffs = PB_TILE + 8 * hi * PB + wj * 128 + 4 * li;
+    f32x2 ra[8];
+    f32x4 rb[8];
+    auto read_raw = [&](int buf, int s) {
+        const float *base = smem + buf * 2 * PB_TILE + 16 * s * PB;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            ra[jj] = *reinterpret_cast<const f32x2 *>(base + aoffs + jj * PB);
+            rb[jj] = ld4(base + boffs + jj * PB);
+        }
+    };
+    f32x16 acc[2][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    };
+    auto step16 = [&](int buf, int s) {
+        read_raw(buf, s);
+        bf16x8 ap[2][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float x[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) x[jj] = ra[jj][a];
+            split8s(x, ap[a][0], ap[a][1], ap[a][2]);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            float x[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) x[jj] = rb[jj][b];
+            bf16x8 bq[3];
+            split8s(x, bq[0], bq[1], bq[2]);
+#define TOAD_T(PA, PB_) \
+            acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][PA], bq[PB_], acc[0][b], 0, 0, 0); \
+            acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1][PA], bq[PB_], acc[1][b], 0, 0, 0);
+            TOAD_T(2, 0) TOAD_T(0, 2) TOAD_T(1, 1) TOAD_T(1, 0) TOAD_T(0, 1) TOAD_T(0, 0)
+#undef TOAD_T
+        }
+    };
+    float bsum = 0.f;
+    auto colsum = [&](int buf, bool on) {
+        if (on && tid < PB) {
+            const float *As = smem + buf * 2 * PB_TILE;
+#pragma unroll 8
+            for (int r = 0; r < BK; ++r) bsum += As[r * PB + tid];
+        }
+    };
+    auto epilogue = [&](int sp, int i0, int j0, bool with_colsum) {
+        int li4 = 4 * li, hi4 = 4 * hi;
+        asm volatile("" : "+v"(li4), "+v"(hi4));
+        float *out = slab + (int64_t)sp * I * J;
+        const int col = j0 + wj * 128 + li4;
+        const bool cok = col < J;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wi * 64 + 2 * ((r & 3) + 8 * (r >> 2) + hi4) + a;
+                f32x4 v = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+                if (cok && row < I) st4(out + (int64_t)row * J + col, v);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (with_colsum && tid < PB && (i0 + tid) < I) colsum_slab[(int64_t)sp * I + i0 + tid] = bsum;
+        bsum = 0.f;
+    };
+
+    int it = 0, nit = 0;
+    int m_stage = 0;
+    set_item(0, m_stage);
+    int cur_sp = item_split(0), cur_i0 = st_i0, cur_j0 = st_j0;
+    int kt = 0, kend = split_steps(cur_sp);
+    int nkt = 0, nkend = kend;
+    bool cur_cs = colsum_slab != nullptr && cur_j0 == 0;
+    dma(0, m_stage);
+    zero_acc();
+    dma_wait();
+    zero_tail(0, m_stage, st_mend);
+    __syncthreads();
+    for (int step = 0; step < total; ++step) {
+        const int buf = step & 1;
+        const bool more = (step + 1) < total;
+        if (more) {
+            if (++nkt == nkend) { ++nit; nkt = 0; set_item(nit, m_stage); nkend = split_steps(item_split(nit)); }
+            else m_stage += BK;
+            dma(buf ^ 1, m_stage);
+        }
+        step16(buf, 0);
+        colsum(buf, cur_cs);
+        step16(buf, 1);
+        dma_wait();
+        if (more) zero_tail(buf ^ 1, m_stage, st_mend);
+        __syncthreads();
+        if (++kt == kend) {
+            epilogue(cur_sp, cur_i0, cur_j0, cur_cs);
+            zero_acc();
+            ++it;
+            if (it < n_items) {
+                cur_sp = item_split(it); kt = 0; kend = split_steps(cur_sp);
+                cur_i0 = st_i0; cur_j0 = st_j0;
+                cur_cs = colsum_slab != nullptr && cur_j0 == 0;
+            }
+        }
+    }
+}
+
 // out[e] = beta*out[e] + sum_s slab[s][e]   (fixed order -> run-to-run deterministic).
 // One launch reduces the weight slabs (n floats each) and, behind them, the bias slabs (n2 each).
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab, float *out, int64_t n,
@@ -1328,8 +1536,19 @@ extern "C" int toad_linear_wgrad_f32(const float *dY, const float *X, float *dW,
         const TnPlan q = tn_plan(M, N, K);
         nsplit = q.nsplit;
         float *cs = db ? slab + (size_t)nsplit * N * K : nullptr;
-        hipLaunchKernelGGL(gemm_tn_f32_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, X, K, slab, cs, (int)M, (int)N,
-                           (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
+        static int tn_split = -1;
+        if (tn_split < 0) {
+            const char *e = getenv("TOAD_GEMM_SPLIT");     // A/B knob
+            tn_split = e ? atoi(e) : 1;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_split_big_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM);
+        }
+        if (tn_split)
+            hipLaunchKernelGGL(gemm_tn_split_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, X, K, slab, cs, (int)M,
+                               (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
+        else
+            hipLaunchKernelGGL(gemm_tn_f32_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, X, K, slab, cs, (int)M,
+                               (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
         rc = check_launch(what);
     } else {
         static bool attr_set = false;
