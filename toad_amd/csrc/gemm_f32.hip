@@ -1214,13 +1214,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_split_big_kernel(
     const int aoffs = 8 * hi * PB + wi * 64 + 2 * li, boffs = PB_TILE + 8 * hi * PB + wj * 128 + 4 * li;
     f32x2 ra[8];
     f32x4 rb[8];
-    auto read_raw = [&](int buf, int s) {
-        const float *base = smem + buf * 2 * PB_TILE + 16 * s * PB;
+    auto read_ra = [&](int buf, int s) {
+        const float *base = smem + buf * 2 * PB_TILE + 16 * s * PB + aoffs;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            ra[jj] = *reinterpret_cast<const f32x2 *>(base + aoffs + jj * PB);
-            rb[jj] = ld4(base + boffs + jj * PB);
-        }
+        for (int jj = 0; jj < 8; ++jj) ra[jj] = *reinterpret_cast<const f32x2 *>(base + jj * PB);
+    };
+    auto read_rb = [&](int buf, int s) {
+        const float *base = smem + buf * 2 * PB_TILE + 16 * s * PB + boffs;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) rb[jj] = ld4(base + jj * PB);
     };
     f32x16 acc[2][4];
     auto zero_acc = [&]() {
@@ -1231,9 +1233,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_split_big_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     };
-    auto step16 = [&](int buf, int s) {
-        read_raw(buf, s);
-        bf16x8 ap[2][3];
+    bf16x8 ap[2][3], bq[3];
+    auto conv_a = [&]() {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             float x[8];
@@ -1241,19 +1242,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_split_big_kernel(
             for (int jj = 0; jj < 8; ++jj) x[jj] = ra[jj][a];
             split8s(x, ap[a][0], ap[a][1], ap[a][2]);
         }
+    };
+    auto conv_b = [&](int b) {
+        float x[8];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            float x[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) x[jj] = rb[jj][b];
-            bf16x8 bq[3];
-            split8s(x, bq[0], bq[1], bq[2]);
+        for (int jj = 0; jj < 8; ++jj) x[jj] = rb[jj][b];
+        split8s(x, bq[0], bq[1], bq[2]);
+    };
+    auto mma12 = [&](int b) {
 #define TOAD_T(PA, PB_) \
-            acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][PA], bq[PB_], acc[0][b], 0, 0, 0); \
-            acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1][PA], bq[PB_], acc[1][b], 0, 0, 0);
-            TOAD_T(2, 0) TOAD_T(0, 2) TOAD_T(1, 1) TOAD_T(1, 0) TOAD_T(0, 1) TOAD_T(0, 0)
+        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][PA], bq[PB_], acc[0][b], 0, 0, 0); \
+        acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1][PA], bq[PB_], acc[1][b], 0, 0, 0);
+        TOAD_T(2, 0) TOAD_T(0, 2) TOAD_T(1, 1) TOAD_T(1, 0) TOAD_T(0, 1) TOAD_T(0, 0)
 #undef TOAD_T
-        }
     };
     float bsum = 0.f;
     auto colsum = [&](int buf, bool on) {
@@ -1295,6 +1296,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_split_big_kernel(
     dma_wait();
     zero_tail(0, m_stage, st_mend);
     __syncthreads();
+    read_ra(0, 0);
+    read_rb(0, 0);
+    // Gather pipeline without a second raw register set: the A gather of the next 16-deep step is re-issued as
+    // soon as A has been split, the B gather right after the LAST B sub-tile has been split (its 12 MFMAs are
+    // still to come), and for the second step of a stage the stage barrier sits at that same point.
     for (int step = 0; step < total; ++step) {
         const int buf = step & 1;
         const bool more = (step + 1) < total;
@@ -1303,12 +1309,31 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_split_big_kernel(
             else m_stage += BK;
             dma(buf ^ 1, m_stage);
         }
-        step16(buf, 0);
+        // ---- 16-deep step 0
+        conv_a();
+        __builtin_amdgcn_sched_barrier(0);
+        read_ra(buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { conv_b(b); mma12(b); }
+        conv_b(3);
+        __builtin_amdgcn_sched_barrier(0);
+        read_rb(buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma12(3);
         colsum(buf, cur_cs);
-        step16(buf, 1);
+        // ---- 16-deep step 1
+        conv_a();
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { conv_b(b); mma12(b); }
+        conv_b(3);
+        __builtin_amdgcn_sched_barrier(0);
         dma_wait();
         if (more) zero_tail(buf ^ 1, m_stage, st_mend);
-        __syncthreads();
+        __syncthreads();                    // next stage landed everywhere; this stage is fully read (ra/rb consumed)
+        if (more) { read_ra(buf ^ 1, 0); read_rb(buf ^ 1, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma12(3);
         if (++kt == kend) {
             epilogue(cur_sp, cur_i0, cur_j0, cur_cs);
             zero_acc();
