@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOAD_ABI_VERSION 5
+#define TOAD_ABI_VERSION 6
 
 enum { TOAD_OK = 0, TOAD_EINVAL = -1, TOAD_ESHAPE = -2, TOAD_EWORKSPACE = -3, TOAD_EALIGN = -4 };
 enum { TOAD_ACT_NONE = 0, TOAD_ACT_RELU = 1 };
@@ -154,6 +154,41 @@ int toad_mtl_ce_fwd_bwd_f32(const float *logits, const float *site_logits,
 int toad_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay,
                        int64_t step, void *stream);
+
+/* ---- Feature extractor: truncated ResNet-50 (models/resnet_custom.py) -------------------- */
+/* Inference form of the reference's `resnet50_baseline` (models/resnet_custom.py:111-119): the producer of the
+ * [N,1024] bags. Activations are NHWC fp32 in HBM, so each convolution is Y[M,Cout] = act(cols[M,K] Wf[Cout,K]^T + bf
+ * (+ residual)) on the same MFMA GEMM as the MIL trunk, with eval-mode BatchNorm folded into Wf / bf by the host. */
+
+/* Y[M,N] = act(X[M,K] W[N,K]^T + bias[N] + residual[M,N]);  bias / residual may be NULL.
+ * = conv (as GEMM) + folded BN [+ `out += residual`] + ReLU: Bottleneck_Baseline.forward, resnet_custom.py:38-53. */
+int toad_linear_act_res_fwd_f32(const float *X, const float *W, const float *bias, const float *residual, float *Y,
+                                int64_t M, int64_t K, int64_t N, int act,
+                                void *ws, size_t ws_bytes, void *stream);
+
+/* cols[m, (ky*kw+kx)*C + c] = X[b, oy*stride-pad+ky, ox*stride-pad+kx, c] (0 outside), m = (b*Ho+oy)*Wo+ox,
+ * Ho = (H+2*pad-kh)/stride+1: the gather that turns nn.Conv2d(C, ., (kh,kw), stride, pad) on an NHWC activation into
+ * the GEMM above (3x3 convs :26-27, strided 1x1 downsample :81-82). C % 4 == 0. */
+int toad_im2col_nhwc_f32(const float *X, float *cols, int B, int H, int W, int C,
+                         int kh, int kw, int stride, int pad, void *stream);
+
+/* The stem's gather, straight from the caller's NCHW tiles [B,3,H,W] (what the reference model is fed):
+ * cols[m, c*49+ky*7+kx] for nn.Conv2d(3,64,7,stride 2,pad 3) (:62), K = 147 zero-padded to 160 columns. */
+int toad_im2col_stem_nchw_f32(const float *X, float *cols, int B, int H, int W, void *stream);
+
+/* nn.MaxPool2d(kernel 3, stride 2, padding 1) (:66) on NHWC; C % 4 == 0. Y is [B, Ho, Wo, C]. */
+int toad_maxpool3x3s2_nhwc_f32(const float *X, float *Y, int B, int H, int W, int C, void *stream);
+
+/* nn.AdaptiveAvgPool2d(1) + view(B,-1) (:70,:104-105): feat[b,c] = mean_p X[b,p,c], X = [B, HW, C]. Deterministic. */
+int toad_avgpool_nhwc_f32(const float *X, float *feat, int B, int HW, int C, void *stream);
+
+/* ResNet_Baseline.forward (:95-108) for layers [3,4,6]: tiles [B,3,H,W] NCHW fp32 -> feat [B,1024], one call, no host
+ * round trips. weights[43] / biases[43]: BN-folded convolutions in execution order (conv1; per block conv1, conv2,
+ * conv3 and, for the first block of a layer, downsample), each [Cout, K] with K = kh*kw*Cin in (ky,kx,c) order - the
+ * stem in (c,ky,kx) order padded to 160. `ws` from toad_resnet50_trunc_ws_bytes (0 = unsupported shape). */
+size_t toad_resnet50_trunc_ws_bytes(int B, int H, int W);
+int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float *const *weights, const float *const *biases,
+                                float *feat, int B, int H, int W, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- Whole per-slide training step ------------------------------------------------------ */
 

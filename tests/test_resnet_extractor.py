@@ -1,0 +1,174 @@
+"""The truncated ResNet-50 feature extractor (SURVEY 8f row 3 / BASELINE config 5).
+CPU: the oracle against the golden captured from the real reference (oracle/pin_resnet_against_reference.py), the
+host module's state-dict surface, BatchNorm folding. GPU: every gather / pool kernel bit-exact against torch, the
+residual GEMM, and the whole network through the C ABI against the reference's features."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import resnet_oracle as ro
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def rg():
+    return np.load(os.path.join(REPO, "tests", "golden", "resnet_golden.npz"), allow_pickle=False)
+
+
+def cases(rg):
+    return sorted({k.split("/")[0] for k in rg.files})
+
+
+def test_oracle_matches_reference_golden_cpu(rg):
+    for name in cases(rg):
+        b, h, w, wseed, xseed = (int(v) for v in rg[name + "/meta"])
+        if h * w * b > 2 * 100 * 100:          # keep the CPU suite short; the 256x256 case runs in the pin script and on the GPU
+            continue
+        f = ro.forward(ro.make_params(wseed), ro.make_tiles(b, h, w, xseed)).numpy()
+        assert f.shape == (b, 1024)
+        assert np.abs(f - rg[name + "/feat"]).max() <= 1e-4, name
+        assert np.abs(f - rg[name + "/feat64"]).max() <= 1e-4, name
+
+
+def test_host_module_surface_and_folding_cpu():
+    from toad_amd.resnet_custom import Bottleneck_Baseline, ResNet_Baseline, resnet50_baseline, _fold
+    torch.manual_seed(0)
+    m = resnet50_baseline()
+    sd = ro.make_params(5)
+    assert list(m.state_dict().keys()) == list(sd.keys())                      # reference key names and order
+    assert all(m.state_dict()[k].shape == sd[k].shape for k in sd)
+    m.load_state_dict(sd, strict=True)
+    assert len(list(m._conv_bn_pairs())) == 43 == len(ro.conv_specs())
+    assert abs(m.layer3[5].conv3.weight.std().item() - (2.0 / (1024 * 1)) ** 0.5) < 2e-3
+    fresh = resnet50_baseline()
+    assert float(fresh.bn1.weight.detach().min()) == 1.0 and float(fresh.layer2[0].downsample[1].bias.detach().abs().max()) == 0.0
+    assert abs(fresh.conv1.weight.std().item() - (2.0 / (64 * 49)) ** 0.5) < 2e-3          # kaiming_normal(fan_out)
+    # folding: conv(x, W) through eval-BN == conv(x, W') + b' for a 3x3 and the stem layout
+    blk = m.layer2[0]
+    x = torch.randn(2, 128, 9, 7)
+    wf, bf = _fold(blk.conv2, blk.bn2, False)
+    ref = F.batch_norm(F.conv2d(x, blk.conv2.weight, stride=2, padding=1), blk.bn2.running_mean, blk.bn2.running_var,
+                       blk.bn2.weight, blk.bn2.bias, False, 0.0, blk.bn2.eps)
+    got = F.conv2d(x, wf.view(128, 3, 3, 128).permute(0, 3, 1, 2), stride=2, padding=1) + bf.view(1, -1, 1, 1)
+    assert (ref - got).abs().max().item() <= 2e-5
+    ws, bs = _fold(m.conv1, m.bn1, True)
+    assert ws.shape == (64, 160) and float(ws[:, 147:].abs().max()) == 0.0
+    x = torch.randn(1, 3, 20, 20)
+    ref = F.batch_norm(F.conv2d(x, m.conv1.weight, stride=2, padding=3), m.bn1.running_mean, m.bn1.running_var, m.bn1.weight, m.bn1.bias, False, 0.0, m.bn1.eps)
+    got = F.conv2d(x, ws[:, :147].view(64, 3, 7, 7), stride=2, padding=3) + bs.view(1, -1, 1, 1)
+    assert (ref - got).abs().max().item() <= 2e-5
+    # refusals: CPU tensors, train mode, pretrained download, other architectures
+    m.eval()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError):
+        resnet50_baseline(pretrained=True)
+    with pytest.raises(NotImplementedError):
+        ResNet_Baseline(Bottleneck_Baseline, [2, 2, 2, 2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,h,w,c,k,s,p", [(2, 16, 16, 64, 3, 1, 1), (1, 13, 9, 128, 3, 2, 1), (3, 8, 8, 256, 1, 2, 0),
+                                           (2, 7, 5, 4, 3, 2, 1), (1, 25, 25, 512, 1, 2, 0), (1, 1, 1, 8, 3, 1, 1)])
+def test_im2col_nhwc_bit_exact(cuda, b, h, w, c, k, s, p):
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(b * 1000 + h * 10 + c)
+    x = torch.randn(b, h, w, c, generator=g)
+    cols = ops.im2col_nhwc(x.to(cuda), k, k, s, p).cpu()
+    u = F.unfold(x.permute(0, 3, 1, 2), k, padding=p, stride=s)                # [B, C*k*k, L], rows ordered (c, ky, kx)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    ref = u.view(b, c, k * k, ho * wo).permute(0, 3, 2, 1).reshape(b * ho * wo, k * k * c)
+    assert torch.equal(cols, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,h,w", [(2, 32, 32), (1, 33, 35), (1, 7, 7), (3, 100, 64)])
+def test_stem_gather_maxpool_avgpool_bit_exact(cuda, b, h, w):
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(h * 100 + w)
+    x = torch.randn(b, 3, h, w, generator=g)
+    cols = ops.im2col_stem_nchw(x.to(cuda)).cpu()
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    ref = F.unfold(x, 7, padding=3, stride=2).permute(0, 2, 1).reshape(b * ho * wo, 147)
+    assert torch.equal(cols[:, :147], ref) and float(cols[:, 147:].abs().max()) == 0.0
+    a = torch.randn(b, h, w, 64, generator=g)                                   # negative values too: padding must not win
+    mp = ops.maxpool3x3s2_nhwc(a.to(cuda)).cpu()
+    assert torch.equal(mp, F.max_pool2d(a.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1))
+    f = torch.randn(b, h * w, 1024, generator=g)
+    ap = ops.avgpool_nhwc(f.to(cuda)).cpu()
+    assert (ap - f.double().mean(1).float()).abs().max().item() <= 1e-6
+    assert torch.equal(ap, ops.avgpool_nhwc(f.to(cuda)).cpu())                  # deterministic
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,n,res,act", [(4096, 64, 64, False, 1), (1000, 576, 64, False, 1), (777, 128, 512, True, 1),
+                                           (2048, 2304, 256, False, 1), (300, 160, 64, False, 1), (512, 256, 1024, True, 0)])
+def test_linear_act_res_matches_fp64(cuda, m, k, n, res, act):
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(m + k + n)
+    x = torch.randn(m, k, generator=g); w = torch.randn(n, k, generator=g) / k ** 0.5; b = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g) if res else None
+    y = ops.linear_act_res_fwd(x.to(cuda), w.to(cuda), b.to(cuda), None if r is None else r.to(cuda), act).cpu()
+    ref = x.double() @ w.double().t() + b.double() + (0 if r is None else r.double())
+    if act:
+        ref = ref.clamp_min(0)
+    assert (y.double() - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.gpu
+def test_extractor_matches_reference_features(cuda, rg):
+    from toad_amd.resnet_custom import resnet50_baseline
+    model = resnet50_baseline()
+    last_seed = None
+    for name in cases(rg):
+        b, h, w, wseed, xseed = (int(v) for v in rg[name + "/meta"])
+        if wseed != last_seed:
+            model.load_state_dict(ro.make_params(wseed), strict=True)
+            model.relocate().eval()
+            last_seed = wseed
+        with torch.no_grad():
+            f = model(ro.make_tiles(b, h, w, xseed).to(cuda)).cpu().numpy()
+        tol = max(1e-4, 4 * float(rg[name + "/dev64"]))
+        assert f.shape == (b, 1024)
+        assert np.abs(f - rg[name + "/feat64"]).max() <= tol, (name, np.abs(f - rg[name + "/feat64"]).max())
+        assert np.abs(f - rg[name + "/feat"]).max() <= tol, name
+    # batch invariance: tile i of a batch == the same tile alone; chunking over MAX_TILES_PER_CALL
+    x = ro.make_tiles(5, 64, 64, 9).to(cuda)
+    with torch.no_grad():
+        full = model(x)
+        one = model(x[3:4])
+    assert (full[3:4] - one).abs().max().item() <= 1e-5
+    import toad_amd.resnet_custom as rc
+    old = rc.MAX_TILES_PER_CALL
+    try:
+        rc.MAX_TILES_PER_CALL = 2
+        with torch.no_grad():
+            assert (model(x) - full).abs().max().item() <= 1e-5
+    finally:
+        rc.MAX_TILES_PER_CALL = old
+    model.train()
+    with pytest.raises(RuntimeError):
+        model(x)
+
+
+@pytest.mark.gpu
+def test_tiles_to_bag_to_mil_forward(cuda):
+    """BASELINE config 5 end to end at toy size: tiles -> extractor -> bag [N,1024] -> MIL forward, against the oracles."""
+    from oracle import toad_oracle as orc
+    from toad_amd import TOAD_fc_mtl_concat
+    from toad_amd.resnet_custom import resnet50_baseline
+    ext = resnet50_baseline(); ext.load_state_dict(ro.make_params(21)); ext.relocate().eval()
+    mil = TOAD_fc_mtl_concat(n_classes=18); params = orc.xavier_params(18, seed=3); mil.load_state_dict(params); mil.relocate(); mil.eval()
+    tiles = ro.make_tiles(24, 64, 64, 77)
+    with torch.no_grad():
+        bag = ext(tiles.to(cuda))
+        out = mil(bag, torch.ones(1, device=cuda))
+    ref_bag = ro.forward(ro.make_params(21), tiles)
+    ref_out, _ = orc.forward(params, ref_bag, torch.ones(1))
+    assert (bag.cpu() - ref_bag).abs().max().item() <= 1e-4
+    assert (out["Y_prob"].cpu() - ref_out["Y_prob"]).abs().max().item() <= 1e-4
+    assert (out["logits"].cpu() - ref_out["logits"]).abs().max().item() <= 1e-3

@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TOAD_HIP_LIB", os.path.join(_HERE, "libtoad_hip.so"))   # override: kernel A/B builds only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 P, I64, I, F, SZ, U64 = c_void_p, c_int64, c_int, c_float, c_size_t, c_uint64
 
@@ -34,6 +34,13 @@ SIGNATURES = {
     "toad_heads_bwd_f32": (I, [P, P, P, P, P, P, P, P, P, P, P, F, I, I, P]),
     "toad_mtl_ce_fwd_bwd_f32": (I, [P, P, P, P, F, F, P, P, P, I, P]),
     "toad_adam_step_f32": (I, [P, P, P, P, I64, F, F, F, F, F, I64, P]),
+    "toad_linear_act_res_fwd_f32": (I, [P, P, P, P, P, I64, I64, I64, I, P, SZ, P]),
+    "toad_im2col_nhwc_f32": (I, [P, P, I, I, I, I, I, I, I, I, P]),
+    "toad_im2col_stem_nchw_f32": (I, [P, P, I, I, I, P]),
+    "toad_maxpool3x3s2_nhwc_f32": (I, [P, P, I, I, I, I, P]),
+    "toad_avgpool_nhwc_f32": (I, [P, P, I, I, I, P]),
+    "toad_resnet50_trunc_ws_bytes": (SZ, [I, I, I]),
+    "toad_resnet50_trunc_fwd_f32": (I, [P, P, P, P, I, I, I, P, SZ, P]),
     "toad_mil_step_ws_bytes": (SZ, [I64, I, I]),
     "toad_mil_step_f32": (I, [P, P, F, P, P, P, P, F, F, I64, I, I, F, U64, P, P, P, P, SZ, P, P]),
 }

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtoad_hip.so")
-SOURCES = ["capi.hip", "gemm_f32.hip", "gated_pool.hip", "heads.hip", "step.hip"]
+SOURCES = ["capi.hip", "gemm_f32.hip", "gated_pool.hip", "heads.hip", "step.hip", "conv.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(REPO, "include", "toad_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
          "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,275 @@
+// conv.hip — the truncated ResNet-50 feature extractor (models/resnet_custom.py:19-119 of the reference) in
+// inference form, as the producer of the [N,1024] bags the MIL path consumes (BASELINE config 5).
+//
+// Design for gfx950: activations live in HBM as NHWC fp32, so every convolution is the NT product the MIL trunk
+// already runs — Y[M, Cout] = act(cols[M, K] . Wf[Cout, K]^T + bf (+ residual)) with M = B*Ho*Wo pixels — on the
+// same persistent split-bf16 MFMA kernel (gemm_f32.hip; fp32-accurate, so the extractor keeps the 1e-4 parity bar).
+// Batch-norm (eval form) is folded into Wf / bf on the host; ReLU and the bottleneck's residual add ride in the GEMM
+// epilogue. 1x1 stride-1 convolutions need no data movement at all (cols == the NHWC activation); 3x3 and strided
+// 1x1 convolutions gather their K = kh*kw*Cin columns with the HBM-bound kernels below (16-B lanes, coalesced on
+// the channel dimension); the 7x7 stem gathers straight from the caller's NCHW tiles.
+#include "common.h"
+
+namespace toad {
+
+// ---- gathers ---------------------------------------------------------------------------------------------------
+// cols[m, (ky*kw + kx)*C + c] = X[b, oy*s - p + ky, ox*s - p + kx, c]  (0 outside), m = (b*Ho + oy)*Wo + ox.
+// One thread per 16-B chunk of a cols row; C % 4 == 0 so a chunk never straddles a tap.
+__global__ __launch_bounds__(256) void im2col_nhwc_kernel(const float *__restrict__ X, float *__restrict__ cols, int B, int H,
+                                                          int W, int C, int Ho, int Wo, int kh, int kw, int stride, int pad) {
+    const uint32_t kq = (uint32_t)(kh * kw * C) >> 2, cq = (uint32_t)C >> 2;
+    const uint64_t total = (uint64_t)B * Ho * Wo * kq;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t m = (uint32_t)(i / kq), j = (uint32_t)(i - (uint64_t)m * kq);
+        const uint32_t tap = j / cq, c4 = j - tap * cq;
+        const int ky = (int)(tap / (uint32_t)kw), kx = (int)(tap - (uint32_t)ky * kw);
+        const uint32_t ox = m % (uint32_t)Wo, t = m / (uint32_t)Wo;
+        const uint32_t oy = t % (uint32_t)Ho, b = t / (uint32_t)Ho;
+        const int iy = (int)oy * stride - pad + ky, ix = (int)ox * stride - pad + kx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4(X + (((uint64_t)b * H + iy) * W + ix) * C + 4 * c4);
+        st4(cols + i * 4, v);
+    }
+}
+
+// The stem: cols[m, c*49 + ky*7 + kx] (K = 147, zero-padded to Kp = 160) from NCHW tiles, 7x7 / stride 2 / pad 3.
+// K keeps the reference's own weight order [Cout, Cin, kh, kw] (resnet_custom.py:62), so kx runs along W in memory.
+__global__ __launch_bounds__(256) void im2col_stem_nchw_kernel(const float *__restrict__ X, float *__restrict__ cols, int B, int H,
+                                                               int W, int Ho, int Wo) {
+    constexpr uint32_t KQ = 40;        // 160 / 4
+    const uint64_t total = (uint64_t)B * Ho * Wo * KQ;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t m = (uint32_t)(i / KQ), j = (uint32_t)(i - (uint64_t)m * KQ);
+        const uint32_t ox = m % (uint32_t)Wo, t = m / (uint32_t)Wo;
+        const uint32_t oy = t % (uint32_t)Ho, b = t / (uint32_t)Ho;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t k = 4 * j + e;
+            float x = 0.f;
+            if (k < 147) {
+                const uint32_t c = k / 49, r = k - c * 49, ky = r / 7, kx = r - ky * 7;
+                const int iy = (int)oy * 2 - 3 + (int)ky, ix = (int)ox * 2 - 3 + (int)kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) x = X[(((uint64_t)b * 3 + c) * H + iy) * W + ix];
+            }
+            v[e] = x;
+        }
+        st4(cols + i * 4, v);
+    }
+}
+
+// nn.MaxPool2d(3, stride 2, padding 1) on NHWC (resnet_custom.py:66): padding never wins the max.
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const float *__restrict__ X, float *__restrict__ Y, int B, int H, int W,
+                                                                int C, int Ho, int Wo) {
+    const uint32_t cq = (uint32_t)C >> 2;
+    const uint64_t total = (uint64_t)B * Ho * Wo * cq;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t m = (uint32_t)(i / cq), c4 = (uint32_t)(i - (uint64_t)m * cq);
+        const uint32_t ox = m % (uint32_t)Wo, t = m / (uint32_t)Wo;
+        const uint32_t oy = t % (uint32_t)Ho, b = t / (uint32_t)Ho;
+        const float ninf = -__builtin_huge_valf();
+        f32x4 best = {ninf, ninf, ninf, ninf};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = (int)oy * 2 - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = (int)ox * 2 - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                const f32x4 v = ld4(X + (((uint64_t)b * H + iy) * W + ix) * C + 4 * c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) best[e] = v[e] > best[e] ? v[e] : best[e];
+            }
+        }
+        st4(Y + i * 4, best);
+    }
+}
+
+// nn.AdaptiveAvgPool2d(1) + flatten (resnet_custom.py:70,104-105): feat[b, c] = mean over the HW pixels of X[b, :, c].
+// Block = (tile b, 256 channels): 4 pixel groups x 64 lanes x 16 B; fixed-order LDS combine -> deterministic.
+__global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const float *__restrict__ X, float *__restrict__ feat, int HW, int C) {
+    __shared__ f32x4 part[4][64];
+    const int b = blockIdx.y, c0 = blockIdx.x * 256;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const bool live = c0 + 4 * lane < C;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float *p = X + (uint64_t)b * HW * C + c0 + 4 * lane;
+        for (int px = grp; px < HW; px += 4) acc += ld4(p + (uint64_t)px * C);
+    }
+    part[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0 && live) {
+        const f32x4 s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        const float inv = 1.f / (float)HW;
+        st4(feat + (uint64_t)b * C + c0 + 4 * lane, s * inv);
+    }
+}
+
+static int grid_for(uint64_t threads) {
+    uint64_t g = (threads + 255) / 256;
+    const uint64_t cap = 256 * 32;                     // 32 blocks per CU is plenty for a streaming gather
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+static inline int conv_out(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+
+// ---- the network plan (shared by the workspace query and the sequencer) -----------------------------------------
+struct ConvSpec { int cin, cout, k, stride, pad; };
+constexpr int kNumConvs = 43;
+struct NetPlan {
+    ConvSpec conv[kNumConvs];
+    size_t act_max, cols_max, gemm_ws;    // floats, floats, bytes
+    int Hs, Ws, Hp, Wp;                   // stem and max-pool output sizes
+};
+static const int kPlanes[3] = {64, 128, 256}, kBlocks[3] = {3, 4, 6}, kStride[3] = {1, 2, 2};
+
+static bool make_plan(int B, int H, int W, NetPlan &p) {
+    if (B <= 0 || H < 1 || W < 1) return false;
+    int n = 0;
+    p.conv[n++] = {3, 64, 7, 2, 3};
+    p.Hs = conv_out(H, 7, 2, 3); p.Ws = conv_out(W, 7, 2, 3);
+    p.Hp = conv_out(p.Hs, 3, 2, 1); p.Wp = conv_out(p.Ws, 3, 2, 1);
+    if (p.Hs < 1 || p.Ws < 1 || p.Hp < 1 || p.Wp < 1) return false;
+    size_t act = (size_t)B * p.Hs * p.Ws * 64, cols = (size_t)B * p.Hs * p.Ws * 160, gws = toad_linear_ws_bytes((int64_t)B * p.Hs * p.Ws, 64, 160);
+    auto upd = [&](size_t M, int cout, int K, bool gathered) {
+        if (M * cout > act) act = M * cout;
+        if (gathered && M * K > cols) cols = M * K;
+        const size_t w = toad_linear_ws_bytes((int64_t)M, cout, K);
+        if (w > gws) gws = w;
+    };
+    int h = p.Hp, w = p.Wp, inpl = 64;
+    for (int l = 0; l < 3; ++l)
+        for (int b = 0; b < kBlocks[l]; ++b) {
+            const int s = b == 0 ? kStride[l] : 1, pl = kPlanes[l];
+            const int ho = conv_out(h, 3, s, 1), wo = conv_out(w, 3, s, 1);
+            p.conv[n++] = {inpl, pl, 1, 1, 0};     upd((size_t)B * h * w, pl, inpl, false);
+            p.conv[n++] = {pl, pl, 3, s, 1};       upd((size_t)B * ho * wo, pl, 9 * pl, true);
+            p.conv[n++] = {pl, 4 * pl, 1, 1, 0};   upd((size_t)B * ho * wo, 4 * pl, pl, false);
+            if (b == 0) { p.conv[n++] = {inpl, 4 * pl, 1, s, 0}; upd((size_t)B * ho * wo, 4 * pl, inpl, s != 1); }
+            inpl = 4 * pl; h = ho; w = wo;
+        }
+    p.act_max = act; p.cols_max = cols; p.gemm_ws = gws;
+    return n == kNumConvs;
+}
+
+static inline size_t align2m(size_t x) { return (x + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1); }
+
+}  // namespace toad
+
+using namespace toad;
+
+extern "C" int toad_im2col_nhwc_f32(const float *X, float *cols, int B, int H, int W, int C, int kh, int kw, int stride,
+                                     int pad, void *stream) {
+    const char *what = "toad_im2col_nhwc_f32";
+    if (!X || !cols) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) { set_error("%s: bad shape (C must be a multiple of 4)", what); return TOAD_ESHAPE; }
+    if (!aligned16(X) || !aligned16(cols)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    const int Ho = conv_out(H, kh, stride, pad), Wo = conv_out(W, kw, stride, pad);
+    if (Ho < 1 || Wo < 1 || (uint64_t)B * Ho * Wo >= (1ull << 32)) { set_error("%s: empty or oversized output", what); return TOAD_ESHAPE; }
+    const uint64_t total = (uint64_t)B * Ho * Wo * (uint64_t)(kh * kw * C / 4);
+    hipLaunchKernelGGL(im2col_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, X, cols, B, H, W, C, Ho, Wo, kh, kw, stride, pad);
+    return check_launch(what);
+}
+
+extern "C" int toad_im2col_stem_nchw_f32(const float *X, float *cols, int B, int H, int W, void *stream) {
+    const char *what = "toad_im2col_stem_nchw_f32";
+    if (!X || !cols) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (B <= 0 || H <= 0 || W <= 0) { set_error("%s: bad shape", what); return TOAD_ESHAPE; }
+    if (!aligned16(cols)) { set_error("%s: cols must be 16-byte aligned", what); return TOAD_EALIGN; }
+    const int Ho = conv_out(H, 7, 2, 3), Wo = conv_out(W, 7, 2, 3);
+    if (Ho < 1 || Wo < 1 || (uint64_t)B * Ho * Wo >= (1ull << 32)) { set_error("%s: empty or oversized output", what); return TOAD_ESHAPE; }
+    hipLaunchKernelGGL(im2col_stem_nchw_kernel, dim3(grid_for((uint64_t)B * Ho * Wo * 40)), dim3(256), 0, (hipStream_t)stream, X, cols, B, H, W, Ho, Wo);
+    return check_launch(what);
+}
+
+extern "C" int toad_maxpool3x3s2_nhwc_f32(const float *X, float *Y, int B, int H, int W, int C, void *stream) {
+    const char *what = "toad_maxpool3x3s2_nhwc_f32";
+    if (!X || !Y) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4) { set_error("%s: bad shape (C must be a multiple of 4)", what); return TOAD_ESHAPE; }
+    if (!aligned16(X) || !aligned16(Y)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    const int Ho = conv_out(H, 3, 2, 1), Wo = conv_out(W, 3, 2, 1);
+    if ((uint64_t)B * Ho * Wo >= (1ull << 32)) { set_error("%s: oversized output", what); return TOAD_ESHAPE; }
+    hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel, dim3(grid_for((uint64_t)B * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, X, Y, B, H, W, C, Ho, Wo);
+    return check_launch(what);
+}
+
+extern "C" int toad_avgpool_nhwc_f32(const float *X, float *feat, int B, int HW, int C, void *stream) {
+    const char *what = "toad_avgpool_nhwc_f32";
+    if (!X || !feat) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (B <= 0 || B > 65535 || HW <= 0 || C <= 0 || C % 4) { set_error("%s: bad shape", what); return TOAD_ESHAPE; }
+    if (!aligned16(X) || !aligned16(feat)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, X, feat, HW, C);
+    return check_launch(what);
+}
+
+extern "C" size_t toad_resnet50_trunc_ws_bytes(int B, int H, int W) {
+    NetPlan p;
+    if (!make_plan(B, H, W, p)) return 0;
+    return 4 * align2m(p.act_max * 4) + align2m(p.cols_max * 4) + align2m(p.gemm_ws) + ((size_t)1 << 21);
+}
+
+// weights[i] : folded conv i as [Cout, K] fp32 (K = kh*kw*Cin in (ky, kx, c) order; the stem keeps (c, ky, kx) padded to 160),
+// biases[i]  : folded BN shift [Cout]; i runs in execution order (conv1, then per block conv1, conv2, conv3[, downsample]).
+extern "C" int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float *const *weights, const float *const *biases,
+                                            float *feat, int B, int H, int W, void *ws, size_t ws_bytes, void *stream) {
+    const char *what = "toad_resnet50_trunc_fwd_f32";
+    if (!tiles_nchw || !weights || !biases || !feat || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    NetPlan p;
+    if (!make_plan(B, H, W, p)) { set_error("%s: bad shape B=%d H=%d W=%d", what, B, H, W); return TOAD_ESHAPE; }
+    if (ws_bytes < toad_resnet50_trunc_ws_bytes(B, H, W)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
+    if (!aligned16(ws) || !aligned16(feat)) { set_error("%s: workspace / output must be 16-byte aligned", what); return TOAD_EALIGN; }
+    for (int i = 0; i < kNumConvs; ++i) if (!weights[i] || !biases[i]) { set_error("%s: null weight/bias slot %d", what, i); return TOAD_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    char *base = reinterpret_cast<char *>(ws);
+    size_t off = align2m(reinterpret_cast<uintptr_t>(ws)) - reinterpret_cast<uintptr_t>(ws);
+    auto take = [&](size_t bytes) { char *q = base + off; off += align2m(bytes); return q; };
+    float *act[4];
+    for (int i = 0; i < 4; ++i) act[i] = reinterpret_cast<float *>(take(p.act_max * 4));
+    float *cols = reinterpret_cast<float *>(take(p.cols_max * 4));
+    void *gws = take(p.gemm_ws);
+    const size_t gcap = p.gemm_ws;
+    int rc;
+#define TOAD_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
+    // stem: 7x7/2 conv + BN + ReLU (resnet_custom.py:96-98), 3x3/2 max-pool (:99)
+    TOAD_TRY(toad_im2col_stem_nchw_f32(tiles_nchw, cols, B, H, W, st));
+    TOAD_TRY(toad_linear_act_res_fwd_f32(cols, weights[0], biases[0], nullptr, act[0], (int64_t)B * p.Hs * p.Ws, 160, 64, TOAD_ACT_RELU, gws, gcap, st));
+    TOAD_TRY(toad_maxpool3x3s2_nhwc_f32(act[0], act[1], B, p.Hs, p.Ws, 64, st));
+    float *x = act[1];                          // block input
+    auto other = [&](float *a0, float *a1, float *a2) {          // a buffer different from the (up to) three in use
+        for (int i = 0; i < 4; ++i) if (act[i] != a0 && act[i] != a1 && act[i] != a2) return act[i];
+        return (float *)nullptr;
+    };
+    int h = p.Hp, w = p.Wp, inpl = 64, ci = 1;
+    for (int l = 0; l < 3; ++l)
+        for (int b = 0; b < kBlocks[l]; ++b) {
+            const int s = b == 0 ? kStride[l] : 1, pl = kPlanes[l];
+            const int ho = conv_out(h, 3, s, 1), wo = conv_out(w, 3, s, 1);
+            const int64_t Mi = (int64_t)B * h * w, Mo = (int64_t)B * ho * wo;
+            float *t1 = other(x, nullptr, nullptr);
+            // conv1 1x1 + BN + ReLU (:38-40): cols == x
+            TOAD_TRY(toad_linear_act_res_fwd_f32(x, weights[ci], biases[ci], nullptr, t1, Mi, inpl, pl, TOAD_ACT_RELU, gws, gcap, st));
+            // conv2 3x3 stride s + BN + ReLU (:42-44)
+            float *t2 = other(x, t1, nullptr);
+            TOAD_TRY(toad_im2col_nhwc_f32(t1, cols, B, h, w, pl, 3, 3, s, 1, st));
+            TOAD_TRY(toad_linear_act_res_fwd_f32(cols, weights[ci + 1], biases[ci + 1], nullptr, t2, Mo, 9 * pl, pl, TOAD_ACT_RELU, gws, gcap, st));
+            // residual: identity, or downsample = strided 1x1 conv + BN (:49-50, :79-85)
+            const float *res = x;
+            float *rbuf = nullptr;
+            if (b == 0) {
+                rbuf = t1;                       // t1 is dead once conv2 has consumed it
+                const float *src = x;
+                if (s != 1) { TOAD_TRY(toad_im2col_nhwc_f32(x, cols, B, h, w, inpl, 1, 1, s, 0, st)); src = cols; }
+                TOAD_TRY(toad_linear_act_res_fwd_f32(src, weights[ci + 3], biases[ci + 3], nullptr, rbuf, Mo, inpl, 4 * pl, TOAD_ACT_NONE, gws, gcap, st));
+                res = rbuf;
+            }
+            // conv3 1x1 + BN, + residual, ReLU (:46-47, :52-53) in one epilogue
+            float *y = other(x, t2, rbuf);
+            TOAD_TRY(toad_linear_act_res_fwd_f32(t2, weights[ci + 2], biases[ci + 2], res, y, Mo, pl, 4 * pl, TOAD_ACT_RELU, gws, gcap, st));
+            ci += b == 0 ? 4 : 3;
+            x = y; inpl = 4 * pl; h = ho; w = wo;
+        }
+#undef TOAD_TRY
+    return toad_avgpool_nhwc_f32(x, feat, B, h * w, inpl, st);
+}

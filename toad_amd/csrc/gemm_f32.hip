@@ -1390,7 +1390,7 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
     if (!aligned16(A) || !aligned16(B) || !aligned16(C)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_SMEM);
         attr_set = true;
     }
     static int use_big = -1;
@@ -1512,6 +1512,17 @@ extern "C" int toad_linear_act_fwd_f32(const float *X, const float *W, const flo
     if (int rc = check_ws(ws, ws_bytes, M, N, K, what)) return rc;
     EpiScalars es{act == TOAD_ACT_RELU, 1.f, make_drop(drop_p, drop_seed)};
     return launch_nt(X, K, W, K, Y, N, M, N, K, bias, es, nullptr, nullptr, ws, (hipStream_t)stream, what);
+}
+
+extern "C" int toad_linear_act_res_fwd_f32(const float *X, const float *W, const float *bias, const float *residual, float *Y,
+                                            int64_t M, int64_t K, int64_t N, int act, void *ws, size_t ws_bytes, void *stream) {
+    const char *what = "toad_linear_act_res_fwd_f32";
+    if (!X || !W || !Y) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (act != TOAD_ACT_NONE && act != TOAD_ACT_RELU) { set_error("%s: bad act %d", what, act); return TOAD_EINVAL; }
+    if (residual && (N % 4 != 0 || !aligned16(residual))) { set_error("%s: residual needs N %% 4 == 0 and 16-byte alignment", what); return TOAD_ESHAPE; }
+    if (int rc = check_ws(ws, ws_bytes, M, N, K, what)) return rc;
+    EpiScalars es{act == TOAD_ACT_RELU, 1.f, make_drop(0.f, 0)};
+    return launch_nt(X, K, W, K, Y, N, M, N, K, bias, es, residual, nullptr, ws, (hipStream_t)stream, what);
 }
 
 extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend, const float *relu_src,

@@ -319,3 +319,58 @@ def mil_step(w, grads, beta: float, bag, sex, label, site, w_cls: float = 0.75, 
         for i, name in enumerate(_GEMM_EVENT_NAMES):
             _TIMING.setdefault(name, []).append((ev_objs[2 + 2 * i], ev_objs[3 + 2 * i]))
     return loss, logits, slog
+
+
+# ---- feature-extractor pieces (conv.hip) --------------------------------------------------------------------------
+def linear_act_res_fwd(x, w, b, residual, act: int) -> torch.Tensor:
+    """Y = act(X W^T + b + residual): a convolution-as-GEMM with folded BN, the bottleneck's skip add and ReLU."""
+    _chk(x, "x"); _chk(w, "w"); _chk(b, "b", allow_none=True); _chk(residual, "residual", allow_none=True)
+    m, k = x.shape
+    n, k2 = w.shape
+    if k != k2 or (b is not None and b.numel() != n) or (residual is not None and tuple(residual.shape) != (m, n)):
+        raise ValueError(f"linear_act_res_fwd: shape mismatch x{tuple(x.shape)} w{tuple(w.shape)}")
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws = _ws(lib.toad_linear_ws_bytes(m, n, k), x.device)
+    _lib.check(lib.toad_linear_act_res_fwd_f32(_p(x), _p(w), _p(b), _p(residual), _p(y), m, k, n, act, _p(ws), ws.numel(),
+                                               _stream()), "toad_linear_act_res_fwd_f32")
+    return y
+
+
+def im2col_nhwc(x: torch.Tensor, kh: int, kw: int, stride: int, pad: int) -> torch.Tensor:
+    """x [B,H,W,C] -> cols [B*Ho*Wo, kh*kw*C], column order (ky, kx, c)."""
+    _chk(x, "x")
+    b, h, w, c = x.shape
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    cols = torch.empty((b * ho * wo, kh * kw * c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().toad_im2col_nhwc_f32(_p(x), _p(cols), b, h, w, c, kh, kw, stride, pad, _stream()), "toad_im2col_nhwc_f32")
+    return cols
+
+
+def im2col_stem_nchw(x: torch.Tensor) -> torch.Tensor:
+    """x [B,3,H,W] -> cols [B*Ho*Wo, 160] for the 7x7/2 pad-3 stem, column order (c, ky, kx), columns 147.. zero."""
+    _chk(x, "x")
+    b, c, h, w = x.shape
+    if c != 3:
+        raise ValueError("im2col_stem_nchw: expected 3 channels")
+    ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    cols = torch.empty((b * ho * wo, 160), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().toad_im2col_stem_nchw_f32(_p(x), _p(cols), b, h, w, _stream()), "toad_im2col_stem_nchw_f32")
+    return cols
+
+
+def maxpool3x3s2_nhwc(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, "x")
+    b, h, w, c = x.shape
+    y = torch.empty((b, (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().toad_maxpool3x3s2_nhwc_f32(_p(x), _p(y), b, h, w, c, _stream()), "toad_maxpool3x3s2_nhwc_f32")
+    return y
+
+
+def avgpool_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """x [B,HW,C] -> [B,C] mean over HW."""
+    _chk(x, "x")
+    b, hw, c = x.shape
+    y = torch.empty((b, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().toad_avgpool_nhwc_f32(_p(x), _p(y), b, hw, c, _stream()), "toad_avgpool_nhwc_f32")
+    return y
