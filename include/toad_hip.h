@@ -166,6 +166,15 @@ int toad_linear_act_res_fwd_f32(const float *X, const float *W, const float *bia
                                 int64_t M, int64_t K, int64_t N, int act,
                                 void *ws, size_t ws_bytes, void *stream);
 
+/* Implicit-GEMM convolution on an NHWC activation, no im2col buffer:
+ *   Y[b,oy,ox,:] = act(sum_{ky,kx,c} X[b, oy*stride-pad+ky, ox*stride-pad+kx, c] * Wf[:, (ky*kw+kx)*Cin + c] + bias (+ residual))
+ * = nn.Conv2d(Cin, Cout, (kh,kw), stride, pad, bias=False) + folded BN [+ skip] + ReLU (resnet_custom.py:26-27,42-44).
+ * The gather happens inside the GEMM's LDS-DMA (per k-stage tap offset, zero fill outside the image).
+ * Needs Cin % 32 == 0 and Cout <= 128 (the narrow-tile kernels); wider layers use toad_im2col_nhwc_f32 + the GEMM. */
+int toad_conv_nhwc_f32(const float *X, const float *Wf, const float *bias, const float *residual, float *Y,
+                       int B, int H, int W, int Cin, int kh, int kw, int stride, int pad, int Cout, int act,
+                       void *ws, size_t ws_bytes, void *stream);
+
 /* cols[m, (ky*kw+kx)*C + c] = X[b, oy*stride-pad+ky, ox*stride-pad+kx, c] (0 outside), m = (b*Ho+oy)*Wo+ox,
  * Ho = (H+2*pad-kh)/stride+1: the gather that turns nn.Conv2d(C, ., (kh,kw), stride, pad) on an NHWC activation into
  * the GEMM above (3x3 convs :26-27, strided 1x1 downsample :81-82). C % 4 == 0. */

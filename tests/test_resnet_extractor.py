@@ -120,6 +120,39 @@ def test_linear_act_res_matches_fp64(cuda, m, k, n, res, act):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,h,w,cin,cout,k,s,p,res", [
+    (2, 16, 16, 64, 64, 3, 1, 1, False),      # layer1 conv2
+    (1, 13, 9, 128, 128, 3, 2, 1, False),     # layer2.0 conv2 (stride 2, odd sizes)
+    (3, 64, 64, 64, 64, 3, 1, 1, False),      # several 512-row tiles per image, many tiles per block
+    (2, 7, 5, 32, 8, 3, 1, 1, True),          # tiny everything, residual, Cout % 32 != 0
+    (1, 25, 25, 256, 128, 1, 2, 0, False),    # strided 1x1 (downsample-like)
+    (5, 10, 12, 96, 100, 3, 1, 1, True),      # Cin not a power of two, ragged Cout
+    (1, 1, 1, 64, 64, 3, 1, 1, False),        # a single pixel: 8 of 9 taps are padding
+    (2, 9, 9, 64, 128, 5, 2, 2, False),       # 5x5
+])
+def test_implicit_conv_matches_fp64(cuda, b, h, w, cin, cout, k, s, p, res):
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(b * 7 + h * 3 + cin + cout)
+    x = torch.randn(b, h, w, cin, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    r = torch.randn(b, ho, wo, cout, generator=g) if res else None
+    wf = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    y = ops.conv_nhwc(x.to(cuda), wf.to(cuda), bias.to(cuda), None if r is None else r.to(cuda), k, k, s, p, 1).cpu()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), stride=s, padding=p).permute(0, 2, 3, 1)
+    if r is not None:
+        ref = ref + r.double()
+    ref = ref.clamp_min(0)
+    assert y.shape == ref.shape
+    assert (y.double() - ref).abs().max().item() <= 2e-5
+    # the implicit gather and the explicit im2col + GEMM are the same arithmetic in the same order
+    cols = ops.im2col_nhwc(x.to(cuda), k, k, s, p)
+    y2 = ops.linear_act_res_fwd(cols, wf.to(cuda), bias.to(cuda), None if r is None else r.to(cuda).view(-1, cout), 1).cpu()
+    assert torch.equal(y.view(-1, cout), y2)
+
+
+@pytest.mark.gpu
 def test_extractor_matches_reference_features(cuda, rg):
     from toad_amd.resnet_custom import resnet50_baseline
     model = resnet50_baseline()

@@ -35,6 +35,7 @@ SIGNATURES = {
     "toad_mtl_ce_fwd_bwd_f32": (I, [P, P, P, P, F, F, P, P, P, I, P]),
     "toad_adam_step_f32": (I, [P, P, P, P, I64, F, F, F, F, F, I64, P]),
     "toad_linear_act_res_fwd_f32": (I, [P, P, P, P, P, I64, I64, I64, I, P, SZ, P]),
+    "toad_conv_nhwc_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, SZ, P]),
     "toad_im2col_nhwc_f32": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "toad_im2col_stem_nchw_f32": (I, [P, P, I, I, I, P]),
     "toad_maxpool3x3s2_nhwc_f32": (I, [P, P, I, I, I, I, P]),

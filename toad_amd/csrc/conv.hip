@@ -154,6 +154,12 @@ static bool make_plan(int B, int H, int W, NetPlan &p) {
     return n == kNumConvs;
 }
 
+static int implicit_conv_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("TOAD_CONV_IMPLICIT"); v = e ? atoi(e) : 1; }   // A/B knob; default on
+    return v;
+}
+
 static inline size_t align2m(size_t x) { return (x + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1); }
 
 }  // namespace toad
@@ -252,8 +258,12 @@ extern "C" int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float 
             TOAD_TRY(toad_linear_act_res_fwd_f32(x, weights[ci], biases[ci], nullptr, t1, Mi, inpl, pl, TOAD_ACT_RELU, gws, gcap, st));
             // conv2 3x3 stride s + BN + ReLU (:42-44)
             float *t2 = other(x, t1, nullptr);
-            TOAD_TRY(toad_im2col_nhwc_f32(t1, cols, B, h, w, pl, 3, 3, s, 1, st));
-            TOAD_TRY(toad_linear_act_res_fwd_f32(cols, weights[ci + 1], biases[ci + 1], nullptr, t2, Mo, 9 * pl, pl, TOAD_ACT_RELU, gws, gcap, st));
+            if (pl <= 128 && implicit_conv_enabled()) {            // gather inside the GEMM's LDS-DMA: no cols buffer
+                TOAD_TRY(toad_conv_nhwc_f32(t1, weights[ci + 1], biases[ci + 1], nullptr, t2, B, h, w, pl, 3, 3, s, 1, pl, TOAD_ACT_RELU, gws, gcap, st));
+            } else {
+                TOAD_TRY(toad_im2col_nhwc_f32(t1, cols, B, h, w, pl, 3, 3, s, 1, st));
+                TOAD_TRY(toad_linear_act_res_fwd_f32(cols, weights[ci + 1], biases[ci + 1], nullptr, t2, Mo, 9 * pl, pl, TOAD_ACT_RELU, gws, gcap, st));
+            }
             // residual: identity, or downsample = strided 1x1 conv + BN (:49-50, :79-85)
             const float *res = x;
             float *rbuf = nullptr;

@@ -1379,8 +1379,321 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// Narrow-N split-bf16 NT kernel, optionally with an implicit convolution gather on the A operand.
+//
+// The persistent 256x256 kernel above wastes 75 % / 50 % of its MFMAs when the weight operand has only 64 / 128 rows
+// (the 1x1 and 3x3 convolutions of ResNet layer1 / layer2, the 7x7 stem). Here all 8 waves sit along M and every wave
+// owns the full tile width: tile = (8 * RA * 32) x (NB * 32) with <RA, NB> = <2, 2> (512 x 64) or <1, 4> (256 x 128);
+// no A fragment is converted twice (the 4x2 wave grid of the big kernel converts every A row in both wave columns).
+// Same arithmetic (x = h + m + l, six terms, small first), same LDS image (XOR-swizzled 128-B fp32 rows for A,
+// column-interleaved pre-swizzled bf16 planes for B), same unit pipeline (B planes one unit ahead, A one k16 step
+// ahead, stage barrier before the last unit), cross-tile pipelining; no K-split (M / TM >> 256 tiles).
+//
+// CONV: A is never materialised. Row m = output pixel (b, oy, ox) of an NHWC activation X[B, H, W, C] (C % 32 == 0) and
+// K = kh * kw * C in (ky, kx, c) order, so k-stage kt lies inside ONE tap (ky, kx) at channel offset c0: each lane's
+// LDS-DMA source is X + ((b*H + oy*s - p + ky)*W + ox*s - p + kx)*C*4 + c0*4 + chunk*16, or - outside the image - a
+// 16-B zero written to the lane's LDS slot instead of the DMA. This deletes the im2col kernels and their 9x HBM
+// write + read traffic: neighbouring taps / tiles hit the same activation lines in the XCD's L2 (tiles are
+// dealt to XCDs in contiguous ranges for that reason).
+// ------------------------------------------------------------------------------------------
+struct ConvGeom { int H, W, C, Ho, Wo, kw, stride, pad; };    // plain ints only (pointers in by-value structs become FLAT)
+
+template <int NB>
+__global__ __launch_bounds__(256) void split_planes_narrow_kernel(const float *__restrict__ src, int64_t sn, unsigned short *__restrict__ Bp,
+                                                                   int N, int K, int tiles_n) {
+    constexpr int TN = NB * 32;
+    const int nk = K / BK;
+    const int64_t total = (int64_t)tiles_n * nk * TN * 4;                 // one thread per (tile, stage, pos, logical chunk)
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int chunk = (int)(t & 3), pos = (int)((t >> 2) % TN);
+        const int64_t ts = (t >> 2) / TN;                                 // tile * nk + stage
+        const int stage = (int)(ts % nk), tile = (int)(ts / nk);
+        const int col = tile * TN + NB * (pos & 31) + (pos >> 5);         // pos = 32 b + li  <->  column NB * li + b
+        const int phys = chunk ^ ((pos >> 2) & 3);
+        unsigned short h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = stage * BK + chunk * 8 + e;
+            const float x = col < N ? src[(int64_t)col * sn + k] : 0.f;
+            const unsigned hb = bf16_rn(__builtin_bit_cast(unsigned, x));
+            const float r1 = x - __builtin_bit_cast(float, hb);
+            const unsigned mb = bf16_rn(__builtin_bit_cast(unsigned, r1));
+            const float r2 = r1 - __builtin_bit_cast(float, mb);
+            h[e] = (unsigned short)(hb >> 16); m[e] = (unsigned short)(mb >> 16);
+            l[e] = (unsigned short)(bf16_rn(__builtin_bit_cast(unsigned, r2)) >> 16);
+        }
+        unsigned short *dst = Bp + ts * (3 * TN * BK) + pos * BK + phys * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dst[e] = h[e]; dst[TN * BK + e] = m[e]; dst[2 * TN * BK + e] = l[e]; }
+    }
+}
+
+template <int RA, int NB> struct NarrowCfg {
+    static constexpr int TM = 8 * RA * 32, TN = NB * 32;
+    static constexpr int A_BYTES = TM * BK * 4, PL_BYTES = TN * BK * 2;
+    static constexpr int STAGE = A_BYTES + 3 * PL_BYTES, SMEM = 2 * STAGE;
+    static constexpr int B_INSTR = 3 * PL_BYTES / 1024;                  // 1 KB (one wave-wide 16-B DMA) each
+    static constexpr int A_INSTR = RA * 4;                                // per wave: 8 rows x 128 B each
+};
+
+template <int RA, int NB, bool CONV>
+__global__ __launch_bounds__(512, 2) void gemm_nt_split_narrow_kernel(
+    const float *__restrict__ A, int64_t lda, const unsigned short *__restrict__ Bp, float *C, int64_t ldc, int M, int N,
+    int K, const float *__restrict__ bias, int relu, const float *addend, ConvGeom cg, int tiles_m, int tiles_n) {
+    using Cfg = NarrowCfg<RA, NB>;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hi = lane >> 5;
+    const int nk = K / BK;
+
+    // ---- work list: XCD x owns a contiguous range of tiles (row-major over (tile_m, tile_n)); slot s of the XCD's
+    // 32 blocks takes tiles s, s + 32, ... of that range, so concurrently running tiles are neighbours in M
+    const int xcd = blockIdx.x % kNumXCD, slot = blockIdx.x / kNumXCD;
+    const int tiles = tiles_m * tiles_n;
+    const int t_lo = (int)(((int64_t)tiles * xcd) / kNumXCD), t_hi = (int)(((int64_t)tiles * (xcd + 1)) / kNumXCD);
+    const int n_items = (t_hi - t_lo - slot + PB_BLOCKS_PER_XCD - 1) / PB_BLOCKS_PER_XCD;
+    if (t_hi - t_lo <= slot) return;
+    auto item_tile = [&](int i) { return t_lo + slot + i * PB_BLOCKS_PER_XCD; };
+    const int total = n_items * nk;
+
+    // ---- staging
+    const char *Bpb = reinterpret_cast<const char *>(Bp);
+    const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned lane16 = lane * 16u;
+    int aoff[Cfg::A_INSTR];              // per-lane byte offset of its row's 16-B chunk (CONV: of pixel (oy*s-p, ox*s-p), may be < 0)
+    int ayx[CONV ? Cfg::A_INSTR : 1];    // CONV: (oy*s - p + 8) << 16 | (ox*s - p + 8)
+    auto dma1 = [&](const char *sbase, unsigned voff, unsigned lds_byte) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+    };
+    auto set_tile = [&](int q, int &m0, int &n0, int &tn) {
+        m0 = (q / tiles_n) * TM;
+        tn = q % tiles_n;
+        n0 = tn * TN;
+#pragma unroll
+        for (int jj = 0; jj < Cfg::A_INSTR; ++jj) {
+            const int p = wave * (RA * 32) + 8 * jj + (lane >> 3);
+            const int ch = (lane & 7) ^ ((p >> 1) & 7);
+            const int m = min(m0 + p, M - 1);
+            if (CONV) {
+                const int ox = m % cg.Wo, t = m / cg.Wo;
+                const int oy = t % cg.Ho, b = t / cg.Ho;
+                const int iy0 = oy * cg.stride - cg.pad, ix0 = ox * cg.stride - cg.pad;
+                aoff[jj] = (((b * cg.H + iy0) * cg.W + ix0) * cg.C) * 4 + ch * 16;
+                ayx[jj] = ((iy0 + 8) << 16) | (ix0 + 8);
+            } else {
+                aoff[jj] = (int)((unsigned)m * (unsigned)(lda * 4)) + ch * 16;
+            }
+        }
+    };
+    // stage cursor of the stage being LOADED: k-stage index and, for CONV, its tap (ky, kx) and channel offset c0
+    struct Cur { int kt, ky, kx, c0; };
+    auto cur_reset = [&](Cur &c) { c.kt = 0; c.ky = 0; c.kx = 0; c.c0 = 0; };
+    auto cur_next = [&](Cur &c) {
+        ++c.kt;
+        if (CONV) { c.c0 += BK; if (c.c0 == cg.C) { c.c0 = 0; if (++c.kx == cg.kw) { c.kx = 0; ++c.ky; } } }
+    };
+    auto dma = [&](int buf, const Cur &c, int tn) {
+        const unsigned dst = lds_base + (unsigned)buf * Cfg::STAGE;
+        const char *Ab = reinterpret_cast<const char *>(A);
+        if (CONV) {
+            const int soff = ((c.ky * cg.W + c.kx) * cg.C + c.c0) * 4;
+#pragma unroll
+            for (int jj = 0; jj < Cfg::A_INSTR; ++jj) {
+                const unsigned ldst = dst + (wave * (RA * 32) + jj * 8) * (BK * 4);
+                const int iy = (ayx[jj] >> 16) - 8 + c.ky, ix = (ayx[jj] & 0xFFFF) - 8 + c.kx;
+                if ((unsigned)iy < (unsigned)cg.H && (unsigned)ix < (unsigned)cg.W) {
+                    dma1(Ab, (unsigned)(aoff[jj] + soff), ldst);
+                } else {
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(smem) + (ldst - lds_base) + lane16) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        } else {
+            const char *ak = Ab + c.kt * (BK * 4);
+#pragma unroll
+            for (int jj = 0; jj < Cfg::A_INSTR; ++jj) dma1(ak, (unsigned)aoff[jj], dst + (wave * (RA * 32) + jj * 8) * (BK * 4));
+        }
+        const char *bk = Bpb + (int64_t)(tn * nk + c.kt) * (3 * Cfg::PL_BYTES);
+#pragma unroll
+        for (int i = 0; i < (Cfg::B_INSTR + 7) / 8; ++i) {
+            const int q = wave + 8 * i;
+            if (q < Cfg::B_INSTR) dma1(bk + q * 1024, lane16, dst + Cfg::A_BYTES + q * 1024);
+        }
+    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+    // ---- fragment addressing
+    const int swA = (li >> 1) & 7, swB = (li >> 2) & 3;
+    const int aposf = (wave * (RA * 32) + li) * BK;                          // floats, + a*32*BK
+    const int bposb = Cfg::A_BYTES + li * 64;                                // bytes, + plane*PL_BYTES + b*32*64
+    auto read_a = [&](int buf, int s, f32x4 (&f)[RA][2]) {
+        const float *base = smem + buf * (Cfg::STAGE / 4) + aposf;
+        const int c0 = ((4 * s + 2 * hi) ^ swA) * 4, c1 = ((4 * s + 2 * hi + 1) ^ swA) * 4;
+#pragma unroll
+        for (int a = 0; a < RA; ++a) { f[a][0] = ld4(base + a * 32 * BK + c0); f[a][1] = ld4(base + a * 32 * BK + c1); }
+    };
+    auto read_b = [&](int buf, int s, int b, bf16x8 (&q)[3]) {
+        const char *base = reinterpret_cast<const char *>(smem) + buf * Cfg::STAGE + bposb + b * 32 * 64 + ((2 * s + hi) ^ swB) * 16;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) q[p] = *reinterpret_cast<const bf16x8 *>(base + p * Cfg::PL_BYTES);
+    };
+    f32x16 acc[RA][NB];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < RA; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    };
+    bf16x8 ap[RA][3], an[RA][3];
+    f32x4 fa[RA][2];
+    bf16x8 bq[3], bn[3];
+    auto convert_a = [&](bf16x8 (&dst)[RA][3]) {
+#pragma unroll
+        for (int a = 0; a < RA; ++a) split8(fa[a][0], fa[a][1], dst[a][0], dst[a][1], dst[a][2]);
+    };
+    auto mma = [&](int b) {              // six terms, small ones first; row sub-tiles alternate
+#define TOAD_T(PA, PB_) \
+        _Pragma("unroll") for (int a = 0; a < RA; ++a) \
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[a][PA], bq[PB_], acc[a][b], 0, 0, 0);
+        TOAD_T(2, 0) TOAD_T(0, 2) TOAD_T(1, 1) TOAD_T(1, 0) TOAD_T(0, 1) TOAD_T(0, 0)
+#undef TOAD_T
+    };
+    auto unit = [&](int b, int nbuf, int ns, int nb, bool fetch, bool conv) {
+        if (fetch) read_b(nbuf, ns, nb, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(b);
+        if (conv) convert_a(an);
+        __builtin_amdgcn_sched_barrier(0);
+        if (fetch) { bq[0] = bn[0]; bq[1] = bn[1]; bq[2] = bn[2]; }
+        if (conv) {
+#pragma unroll
+            for (int a = 0; a < RA; ++a)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) ap[a][p] = an[a][p];
+        }
+    };
+
+    typedef float fvec __attribute__((ext_vector_type(NB)));
+    auto epilogue = [&](int m0, int n0) {
+        int lic = NB * li, hi4 = 4 * hi;
+        asm volatile("" : "+v"(lic), "+v"(hi4));
+        const int col = n0 + lic;
+        const bool cok = col < N;
+        fvec bv;
+#pragma unroll
+        for (int e = 0; e < NB; ++e) bv[e] = 0.f;
+        if (bias && cok) bv = *reinterpret_cast<const fvec *>(bias + col);
+        asm volatile("" : "+v"(bv));
+#pragma unroll
+        for (int a = 0; a < RA; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wave * (RA * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + hi4;
+                if (cok && row < M) {
+                    fvec v;
+#pragma unroll
+                    for (int e = 0; e < NB; ++e) v[e] = acc[a][e][r];
+                    const int64_t off = (int64_t)row * ldc + col;
+                    v += bv;
+                    if (addend) v += *reinterpret_cast<const fvec *>(addend + off);
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < NB; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    }
+                    __builtin_nontemporal_store(v, reinterpret_cast<fvec *>(C + off));
+                }
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    int kt = 0, nit = 0;
+    Cur nc;
+    cur_reset(nc);
+    int cur_m0, cur_n0, cur_tn, nxt_m0, nxt_n0, nxt_tn;
+    set_tile(item_tile(0), cur_m0, cur_n0, cur_tn);
+    nxt_m0 = cur_m0; nxt_n0 = cur_n0; nxt_tn = cur_tn;
+    dma(0, nc, cur_tn);
+    zero_acc();
+    dma_wait();
+    __syncthreads();
+    read_a(0, 0, fa);
+    read_b(0, 0, 0, bq);
+    convert_a(ap);
+    for (int step = 0; step < total; ++step) {
+        const int buf = step & 1;
+        const bool more = (step + 1) < total;
+        if (more) {
+            cur_next(nc);
+            if (nc.kt == nk) { ++nit; cur_reset(nc); set_tile(item_tile(nit), nxt_m0, nxt_n0, nxt_tn); }
+            dma(buf ^ 1, nc, nxt_tn);
+        }
+        // k16 step 0: units 0..NB-1 (raw A of step 1 is fetched up front and split during the last unit)
+        read_a(buf, 1, fa);
+#pragma unroll
+        for (int b = 0; b < NB - 1; ++b) unit(b, buf, 0, b + 1, true, false);
+        unit(NB - 1, buf, 1, 0, true, true);
+        // k16 step 1
+#pragma unroll
+        for (int b = 0; b < NB - 1; ++b) unit(b, buf, 1, b + 1, true, false);
+        dma_wait();
+        __syncthreads();                    // next stage landed everywhere; this stage is fully read
+        if (more) read_a(buf ^ 1, 0, fa);
+        unit(NB - 1, buf ^ 1, 0, 0, more, more);
+        if (++kt == nk) {
+            epilogue(cur_m0, cur_n0);
+            zero_acc();
+            kt = 0;
+            cur_m0 = nxt_m0; cur_n0 = nxt_n0; cur_tn = nxt_tn;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+static int narrow_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("TOAD_GEMM_NARROW"); v = e ? atoi(e) : 1; }   // A/B knob; default on
+    return v;
+}
+
+// C[M,N] = act(A' W^T + bias + addend) with N <= 128 on the narrow kernels; A' = A[M,K] (geom == nullptr) or the implicit
+// im2col of the NHWC activation A described by *geom. `ws` as for launch_nt (the bf16 planes live behind the slab area).
+template <int RA, int NB, bool CONV>
+static int launch_narrow_t(const float *A, int64_t lda, const float *W, int64_t ldw, float *C, int64_t ldc, int64_t M, int64_t N,
+                           int64_t K, const float *bias, int relu, const float *addend, const ConvGeom &cg, void *ws,
+                           hipStream_t st, const char *what) {
+    using Cfg = NarrowCfg<RA, NB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_split_narrow_kernel<RA, NB, CONV>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+        attr_set = true;
+    }
+    const int tiles_m = (int)((M + Cfg::TM - 1) / Cfg::TM), tiles_n = (int)((N + Cfg::TN - 1) / Cfg::TN);
+    unsigned short *planes = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(ws) + (size_t)PB_GRID * PB * PB * sizeof(float));
+    const int64_t pthreads = (int64_t)tiles_n * (K / BK) * Cfg::TN * 4;
+    int pgrid = (int)((pthreads + 255) / 256);
+    if (pgrid > 4096) pgrid = 4096;
+    hipLaunchKernelGGL(split_planes_narrow_kernel<NB>, dim3(pgrid), dim3(256), 0, st, W, ldw, planes, (int)N, (int)K, tiles_n);
+    int rc = check_launch(what);
+    if (rc) return rc;
+    hipLaunchKernelGGL((gemm_nt_split_narrow_kernel<RA, NB, CONV>), dim3(PB_GRID), dim3(512), Cfg::SMEM, st, A, lda, planes, C, ldc,
+                       (int)M, (int)N, (int)K, bias, relu, addend, cg, tiles_m, tiles_n);
+    return check_launch(what);
+}
+
+static bool narrow_ok(int64_t M, int64_t N, int64_t K, int64_t ldc, const float *bias, const float *addend, void *ws) {
+    return narrow_enabled() && ws && N <= 128 && N % 4 == 0 && K % BK == 0 && ldc % 4 == 0 && M < (1ll << 31) &&
+           (!bias || aligned16(bias)) && (!addend || aligned16(addend));
+}
+
 static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
                      const float *mask_src, void *ws, hipStream_t st, const char *what) {
@@ -1407,6 +1720,12 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
         use_split = e ? atoi(e) : 1;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_split_big_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SP_SMEM);
+    }
+    if (use_big && use_split && !es.drop.thresh && !mask_src && ldb == K && (uint64_t)M * lda * 4 < (1ull << 32) &&
+        narrow_ok(M, N, K, ldc, bias, addend, ws)) {
+        const ConvGeom none{0, 0, 0, 0, 0, 0, 0, 0};
+        if (N <= 64) return launch_narrow_t<2, 2, false>(A, lda, B, ldb, C, ldc, M, N, K, bias, es.relu, addend, none, ws, st, what);
+        return launch_narrow_t<1, 4, false>(A, lda, B, ldb, C, ldc, M, N, K, bias, es.relu, addend, none, ws, st, what);
     }
     if (use_big && use_split && ws && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && (uint64_t)M * lda * 4 < (1ull << 32)) {
         // B is given as B[n, k] = Bsrc[n * bsn + k * bsk]; split it into pre-swizzled bf16 planes behind the slabs
@@ -1523,6 +1842,28 @@ extern "C" int toad_linear_act_res_fwd_f32(const float *X, const float *W, const
     if (int rc = check_ws(ws, ws_bytes, M, N, K, what)) return rc;
     EpiScalars es{act == TOAD_ACT_RELU, 1.f, make_drop(0.f, 0)};
     return launch_nt(X, K, W, K, Y, N, M, N, K, bias, es, residual, nullptr, ws, (hipStream_t)stream, what);
+}
+
+extern "C" int toad_conv_nhwc_f32(const float *X, const float *Wf, const float *bias, const float *residual, float *Y, int B, int H,
+                                  int W, int Cin, int kh, int kw, int stride, int pad, int Cout, int act, void *ws, size_t ws_bytes,
+                                  void *stream) {
+    const char *what = "toad_conv_nhwc_f32";
+    if (!X || !Wf || !Y || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (act != TOAD_ACT_NONE && act != TOAD_ACT_RELU) { set_error("%s: bad act %d", what, act); return TOAD_EINVAL; }
+    if (B <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0 || pad > 8 || H + 8 >= 32768 || W + 8 >= 32768) { set_error("%s: bad geometry", what); return TOAD_ESHAPE; }
+    if (Cin <= 0 || Cin % BK != 0) { set_error("%s: Cin must be a multiple of %d (use toad_im2col_nhwc_f32 + toad_linear_act_res_fwd_f32 otherwise)", what, BK); return TOAD_ESHAPE; }
+    if (Cout <= 0 || Cout > 128 || Cout % 4 != 0) { set_error("%s: implicit path needs Cout <= 128, a multiple of 4 (use im2col + linear for wider layers)", what); return TOAD_ESHAPE; }
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    if (Ho < 1 || Wo < 1) { set_error("%s: empty output", what); return TOAD_ESHAPE; }
+    const int64_t M = (int64_t)B * Ho * Wo, K = (int64_t)kh * kw * Cin;
+    if ((uint64_t)B * H * W * Cin * 4 >= (1ull << 31) || M >= (1ll << 31)) { set_error("%s: activation too large for 32-bit offsets (split the batch)", what); return TOAD_ESHAPE; }
+    if (!aligned16(X) || !aligned16(Wf) || !aligned16(Y)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (int rc = check_ws(ws, ws_bytes, M, Cout, K, what)) return rc;
+    if (!narrow_ok(M, Cout, K, Cout, bias, residual, ws)) { set_error("%s: bias / residual must be 16-byte aligned", what); return TOAD_EALIGN; }
+    const ConvGeom cg{H, W, Cin, Ho, Wo, kw, stride, pad};
+    if (Cout <= 64)
+        return launch_narrow_t<2, 2, true>(X, 0, Wf, K, Y, Cout, M, Cout, K, bias, act == TOAD_ACT_RELU, residual, cg, ws, (hipStream_t)stream, what);
+    return launch_narrow_t<1, 4, true>(X, 0, Wf, K, Y, Cout, M, Cout, K, bias, act == TOAD_ACT_RELU, residual, cg, ws, (hipStream_t)stream, what);
 }
 
 extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend, const float *relu_src,

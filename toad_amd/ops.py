@@ -337,6 +337,22 @@ def linear_act_res_fwd(x, w, b, residual, act: int) -> torch.Tensor:
     return y
 
 
+def conv_nhwc(x: torch.Tensor, wf: torch.Tensor, b, residual, kh: int, kw: int, stride: int, pad: int, act: int) -> torch.Tensor:
+    """Implicit-GEMM convolution: x [B,H,W,Cin] NHWC, wf [Cout, kh*kw*Cin] in (ky,kx,c) order -> [B,Ho,Wo,Cout]."""
+    _chk(x, "x"); _chk(wf, "wf"); _chk(b, "b", allow_none=True); _chk(residual, "residual", allow_none=True)
+    bb, h, w, c = x.shape
+    cout = wf.shape[0]
+    if wf.shape[1] != kh * kw * c:
+        raise ValueError("conv_nhwc: weight shape mismatch")
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    y = torch.empty((bb, ho, wo, cout), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws = _ws(lib.toad_linear_ws_bytes(bb * ho * wo, cout, kh * kw * c), x.device)
+    _lib.check(lib.toad_conv_nhwc_f32(_p(x), _p(wf), _p(b), _p(residual), _p(y), bb, h, w, c, kh, kw, stride, pad, cout, act,
+                                      _p(ws), ws.numel(), _stream()), "toad_conv_nhwc_f32")
+    return y
+
+
 def im2col_nhwc(x: torch.Tensor, kh: int, kw: int, stride: int, pad: int) -> torch.Tensor:
     """x [B,H,W,C] -> cols [B*Ho*Wo, kh*kw*C], column order (ky, kx, c)."""
     _chk(x, "x")
