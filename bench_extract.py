@@ -142,7 +142,7 @@ def main():
                                       f"in chunks of {chunk} -> bag [{n},1024] -> TOAD_fc_mtl_concat(big, 18 classes) fwd + CE + bwd + Adam",
                           "arithmetic": "fp32 storage/accumulation; conv-as-GEMM products as split-bf16 (6 MFMA terms) = fp32-equivalent",
                           "parallelism": f"slide-sharded dp{world}"},
-               "roofline": {"bound": "mfma", "kernel": "gemm_nt_split_big_kernel x43 per chunk (+ im2col gathers, pools)",
+               "roofline": {"bound": "mfma", "kernel": "43 conv-as-GEMM launches per chunk: gemm_nt_split_narrow_kernel<2,2|1,4> (Cout <= 128, implicit 3x3 gather) + gemm_nt_split_big_kernel (Cout >= 256); + stem/strided gathers, pools",
                             "achieved": round(tf / 1e12, 2), "peak": round(MFMA_EQ_PEAK / 1e12, 1), "unit": "TFLOP/s fp32-equivalent",
                             "frac": round(tf / MFMA_EQ_PEAK, 4), "traffic": None, "bf16_mfma_tflops_issued": round(tf * SPLIT_TERMS / 1e12, 1),
                             "algorithmic_flops": FLOP_PER_TILE * n, "extractor_ms_per_step": round(ext_ms, 3),
