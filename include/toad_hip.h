@@ -185,6 +185,15 @@ int toad_im2col_nhwc_f32(const float *X, float *cols, int B, int H, int W, int C
  * cols[m, c*49+ky*7+kx] for nn.Conv2d(3,64,7,stride 2,pad 3) (:62), K = 147 zero-padded to 160 columns. */
 int toad_im2col_stem_nchw_f32(const float *X, float *cols, int B, int H, int W, void *stream);
 
+/* The stem without a cols buffer. toad_stem_s2d_nchw_f32 writes the space-to-depth image
+ *   Xs[b, Y, X, (ry*2+rx)*3 + c] = x[b, c, 2Y+ry-4, 2X+rx-4] (0 outside),  Y < Ho+3, X < Wo+3,  Ho = (H-1)/2+1, Wo = (W-1)/2+1
+ * and toad_stem_conv_s2d_f32 computes nn.Conv2d(3,64,7,stride 2,pad 3) + folded BN (+ReLU) (:62-64,:96-98) from it as a 4x4/1
+ * convolution gathered inside the GEMM:  Y[b,oy,ox,:] = act(sum_{qy,qx<4; j<12} Xs[b,oy+qy,ox+qx,j] * Wf[:, qy*48+qx*12+j] + bias),
+ * Wf[:, qy*48 + qx*12 + (ry*2+rx)*3 + c] = w[:, c, 2qy+ry-1, 2qx+rx-1] (0 where an index is -1): [64,192]. Y is NHWC [B,Ho,Wo,64]. */
+int toad_stem_s2d_nchw_f32(const float *X, float *Xs, int B, int H, int W, void *stream);
+int toad_stem_conv_s2d_f32(const float *Xs, const float *Wf, const float *bias, float *Y, int B, int Ho, int Wo, int act,
+                           void *ws, size_t ws_bytes, void *stream);
+
 /* nn.MaxPool2d(kernel 3, stride 2, padding 1) (:66) on NHWC; C % 4 == 0. Y is [B, Ho, Wo, C]. */
 int toad_maxpool3x3s2_nhwc_f32(const float *X, float *Y, int B, int H, int W, int C, void *stream);
 
@@ -194,7 +203,7 @@ int toad_avgpool_nhwc_f32(const float *X, float *feat, int B, int HW, int C, voi
 /* ResNet_Baseline.forward (:95-108) for layers [3,4,6]: tiles [B,3,H,W] NCHW fp32 -> feat [B,1024], one call, no host
  * round trips. weights[43] / biases[43]: BN-folded convolutions in execution order (conv1; per block conv1, conv2,
  * conv3 and, for the first block of a layer, downsample), each [Cout, K] with K = kh*kw*Cin in (ky,kx,c) order - the
- * stem in (c,ky,kx) order padded to 160. `ws` from toad_resnet50_trunc_ws_bytes (0 = unsupported shape). */
+ * stem as the [64,192] space-to-depth operand of toad_stem_conv_s2d_f32. `ws` from toad_resnet50_trunc_ws_bytes (0 = unsupported shape). */
 size_t toad_resnet50_trunc_ws_bytes(int B, int H, int W);
 int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float *const *weights, const float *const *biases,
                                 float *feat, int B, int H, int W, void *ws, size_t ws_bytes, void *stream);

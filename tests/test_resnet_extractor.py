@@ -55,12 +55,21 @@ def test_host_module_surface_and_folding_cpu():
                        blk.bn2.weight, blk.bn2.bias, False, 0.0, blk.bn2.eps)
     got = F.conv2d(x, wf.view(128, 3, 3, 128).permute(0, 3, 1, 2), stride=2, padding=1) + bf.view(1, -1, 1, 1)
     assert (ref - got).abs().max().item() <= 2e-5
-    ws, bs = _fold(m.conv1, m.bn1, True)
-    assert ws.shape == (64, 160) and float(ws[:, 147:].abs().max()) == 0.0
+    ws, bs = _fold(m.conv1, m.bn1, True)                 # [64, 192]: (qy, qx, ry, rx, c) space-to-depth order
+    assert ws.shape == (64, 192)
+    w8 = ws.view(64, 4, 4, 2, 2, 3).permute(0, 5, 1, 3, 2, 4).reshape(64, 3, 8, 8)     # slot 2q + r holds tap 2q + r - 1
+    assert float(w8[:, :, 0, :].abs().max()) == 0.0 and float(w8[:, :, :, 0].abs().max()) == 0.0
     x = torch.randn(1, 3, 20, 20)
     ref = F.batch_norm(F.conv2d(x, m.conv1.weight, stride=2, padding=3), m.bn1.running_mean, m.bn1.running_var, m.bn1.weight, m.bn1.bias, False, 0.0, m.bn1.eps)
-    got = F.conv2d(x, ws[:, :147].view(64, 3, 7, 7), stride=2, padding=3) + bs.view(1, -1, 1, 1)
+    got = F.conv2d(x, w8[:, :, 1:, 1:].contiguous(), stride=2, padding=3) + bs.view(1, -1, 1, 1)
     assert (ref - got).abs().max().item() <= 2e-5
+    # the same operand applied the way the kernel does: 4x4 / stride-1 convolution over the 12-channel space-to-depth image
+    xp = F.pad(x, (4, 4 + 8, 4, 4 + 8))                                                  # iy' = iy + 4, generous zero tail
+    xs = xp.unfold(2, 2, 2).unfold(3, 2, 2)                                             # [1, 3, Y, X, ry, rx]
+    xs = xs.permute(0, 2, 3, 4, 5, 1).reshape(1, xs.shape[2], xs.shape[3], 12)          # channel = (ry*2 + rx)*3 + c
+    k = ws.view(64, 4, 4, 12).permute(0, 3, 1, 2)                                       # [64, 12, qy, qx]
+    got2 = F.conv2d(xs.permute(0, 3, 1, 2), k)[:, :, :10, :10] + bs.view(1, -1, 1, 1)
+    assert (ref - got2).abs().max().item() <= 2e-5
     # refusals: CPU tensors, train mode, pretrained download, other architectures
     m.eval()
     with pytest.raises(RuntimeError):
@@ -95,6 +104,14 @@ def test_stem_gather_maxpool_avgpool_bit_exact(cuda, b, h, w):
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     ref = F.unfold(x, 7, padding=3, stride=2).permute(0, 2, 1).reshape(b * ho * wo, 147)
     assert torch.equal(cols[:, :147], ref) and float(cols[:, 147:].abs().max()) == 0.0
+    # the shipped stem: space-to-depth image + implicit 4x4 gather, against fp64 conv2d
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    bias = torch.randn(64, generator=g)
+    w8 = torch.zeros(64, 3, 8, 8); w8[:, :, 1:, 1:] = wt
+    wf = w8.view(64, 3, 4, 2, 4, 2).permute(0, 2, 4, 3, 5, 1).reshape(64, 192).contiguous()
+    y = ops.stem_conv(x.to(cuda), wf.to(cuda), bias.to(cuda), 1).cpu()
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), stride=2, padding=3).clamp_min(0).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape and (y.double() - ref).abs().max().item() <= 2e-5
     a = torch.randn(b, h, w, 64, generator=g)                                   # negative values too: padding must not win
     mp = ops.maxpool3x3s2_nhwc(a.to(cuda)).cpu()
     assert torch.equal(mp, F.max_pool2d(a.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1))

@@ -38,6 +38,8 @@ SIGNATURES = {
     "toad_conv_nhwc_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, SZ, P]),
     "toad_im2col_nhwc_f32": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "toad_im2col_stem_nchw_f32": (I, [P, P, I, I, I, P]),
+    "toad_stem_s2d_nchw_f32": (I, [P, P, I, I, I, P]),
+    "toad_stem_conv_s2d_f32": (I, [P, P, P, P, I, I, I, I, P, SZ, P]),
     "toad_maxpool3x3s2_nhwc_f32": (I, [P, P, I, I, I, I, P]),
     "toad_avgpool_nhwc_f32": (I, [P, P, I, I, I, P]),
     "toad_resnet50_trunc_ws_bytes": (SZ, [I, I, I]),

@@ -58,6 +58,33 @@ __global__ __launch_bounds__(256) void im2col_stem_nchw_kernel(const float *__re
     }
 }
 
+// Space-to-depth image of the stem: Xs[b, Y, X, (ry*2 + rx)*3 + c] = x[b, c, 2Y + ry - 4, 2X + rx - 4] (0 outside), Y < Ho + 3,
+// X < Wo + 3. With it the 7x7 / stride-2 / pad-3 convolution (resnet_custom.py:62) becomes a 4x4 / stride-1 one whose K row
+// for output pixel (oy, ox) is 4 window rows of 48 CONTIGUOUS floats (Xs[b, oy+qy, ox..ox+3, :]), i.e. something the GEMM's
+// LDS-DMA can gather by itself: tap ky = 2*qy + ry - 1, kx = 2*qx + rx - 1 (the -1 slots carry zero weights). One thread per
+// (b, Y, X): 12 reads that are pairwise adjacent in NCHW memory, 48 contiguous bytes written.
+__global__ __launch_bounds__(256) void stem_s2d_kernel(const float *__restrict__ X, float *__restrict__ Xs, int B, int H, int W, int Hs, int Ws) {
+    const uint64_t total = (uint64_t)B * Hs * Ws;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t xs = (uint32_t)(i % (uint32_t)Ws), t = (uint32_t)(i / (uint32_t)Ws);
+        const uint32_t ys = t % (uint32_t)Hs, b = t / (uint32_t)Hs;
+        float v[12];
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry) {
+            const int iy = 2 * (int)ys + ry - 4;
+#pragma unroll
+            for (int rx = 0; rx < 2; ++rx) {
+                const int ix = 2 * (int)xs + rx - 4;
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[(ry * 2 + rx) * 3 + c] = ok ? X[(((uint64_t)b * 3 + c) * H + iy) * W + ix] : 0.f;
+            }
+        }
+        float *dst = Xs + i * 12;
+        st4(dst, f32x4{v[0], v[1], v[2], v[3]}); st4(dst + 4, f32x4{v[4], v[5], v[6], v[7]}); st4(dst + 8, f32x4{v[8], v[9], v[10], v[11]});
+    }
+}
+
 // nn.MaxPool2d(3, stride 2, padding 1) on NHWC (resnet_custom.py:66): padding never wins the max.
 __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const float *__restrict__ X, float *__restrict__ Y, int B, int H, int W,
                                                                 int C, int Ho, int Wo) {
@@ -132,7 +159,7 @@ static bool make_plan(int B, int H, int W, NetPlan &p) {
     p.Hs = conv_out(H, 7, 2, 3); p.Ws = conv_out(W, 7, 2, 3);
     p.Hp = conv_out(p.Hs, 3, 2, 1); p.Wp = conv_out(p.Ws, 3, 2, 1);
     if (p.Hs < 1 || p.Ws < 1 || p.Hp < 1 || p.Wp < 1) return false;
-    size_t act = (size_t)B * p.Hs * p.Ws * 64, cols = (size_t)B * p.Hs * p.Ws * 160, gws = toad_linear_ws_bytes((int64_t)B * p.Hs * p.Ws, 64, 160);
+    size_t act = (size_t)B * p.Hs * p.Ws * 64, cols = (size_t)B * (p.Hs + 3) * (p.Ws + 3) * 12, gws = toad_linear_ws_bytes((int64_t)B * p.Hs * p.Ws, 64, 192);
     auto upd = [&](size_t M, int cout, int K, bool gathered) {
         if (M * cout > act) act = M * cout;
         if (gathered && M * K > cols) cols = M * K;
@@ -190,6 +217,16 @@ extern "C" int toad_im2col_stem_nchw_f32(const float *X, float *cols, int B, int
     return check_launch(what);
 }
 
+extern "C" int toad_stem_s2d_nchw_f32(const float *X, float *Xs, int B, int H, int W, void *stream) {
+    const char *what = "toad_stem_s2d_nchw_f32";
+    if (!X || !Xs) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (B <= 0 || H <= 0 || W <= 0) { set_error("%s: bad shape", what); return TOAD_ESHAPE; }
+    if (!aligned16(Xs)) { set_error("%s: Xs must be 16-byte aligned", what); return TOAD_EALIGN; }
+    const int Hs = conv_out(H, 7, 2, 3) + 3, Ws = conv_out(W, 7, 2, 3) + 3;
+    hipLaunchKernelGGL(stem_s2d_kernel, dim3(grid_for((uint64_t)B * Hs * Ws)), dim3(256), 0, (hipStream_t)stream, X, Xs, B, H, W, Hs, Ws);
+    return check_launch(what);
+}
+
 extern "C" int toad_maxpool3x3s2_nhwc_f32(const float *X, float *Y, int B, int H, int W, int C, void *stream) {
     const char *what = "toad_maxpool3x3s2_nhwc_f32";
     if (!X || !Y) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
@@ -216,7 +253,8 @@ extern "C" size_t toad_resnet50_trunc_ws_bytes(int B, int H, int W) {
     return 4 * align2m(p.act_max * 4) + align2m(p.cols_max * 4) + align2m(p.gemm_ws) + ((size_t)1 << 21);
 }
 
-// weights[i] : folded conv i as [Cout, K] fp32 (K = kh*kw*Cin in (ky, kx, c) order; the stem keeps (c, ky, kx) padded to 160),
+// weights[i] : folded conv i as [Cout, K] fp32 (K = kh*kw*Cin in (ky, kx, c) order; the stem is [64, 192] in the space-to-depth
+//              order of toad_stem_conv_s2d_f32),
 // biases[i]  : folded BN shift [Cout]; i runs in execution order (conv1, then per block conv1, conv2, conv3[, downsample]).
 extern "C" int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float *const *weights, const float *const *biases,
                                             float *feat, int B, int H, int W, void *ws, size_t ws_bytes, void *stream) {
@@ -239,8 +277,8 @@ extern "C" int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float 
     int rc;
 #define TOAD_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
     // stem: 7x7/2 conv + BN + ReLU (resnet_custom.py:96-98), 3x3/2 max-pool (:99)
-    TOAD_TRY(toad_im2col_stem_nchw_f32(tiles_nchw, cols, B, H, W, st));
-    TOAD_TRY(toad_linear_act_res_fwd_f32(cols, weights[0], biases[0], nullptr, act[0], (int64_t)B * p.Hs * p.Ws, 160, 64, TOAD_ACT_RELU, gws, gcap, st));
+    TOAD_TRY(toad_stem_s2d_nchw_f32(tiles_nchw, cols, B, H, W, st));              // 12-channel space-to-depth image (53 MB per 64 tiles)
+    TOAD_TRY(toad_stem_conv_s2d_f32(cols, weights[0], biases[0], act[0], B, p.Hs, p.Ws, TOAD_ACT_RELU, gws, gcap, st));
     TOAD_TRY(toad_maxpool3x3s2_nhwc_f32(act[0], act[1], B, p.Hs, p.Ws, 64, st));
     float *x = act[1];                          // block input
     auto other = [&](float *a0, float *a1, float *a2) {          // a buffer different from the (up to) three in use

@@ -1397,6 +1397,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 // dealt to XCDs in contiguous ranges for that reason).
 // ------------------------------------------------------------------------------------------
 struct ConvGeom { int H, W, C, Ho, Wo, kw, stride, pad; };    // plain ints only (pointers in by-value structs become FLAT)
+enum { GATHER_NONE = 0, GATHER_CONV = 1, GATHER_STEM = 2 };     // how the A operand of the narrow kernel is addressed
 
 template <int NB>
 __global__ __launch_bounds__(256) void split_planes_narrow_kernel(const float *__restrict__ src, int64_t sn, unsigned short *__restrict__ Bp,
@@ -1436,7 +1437,7 @@ template <int RA, int NB> struct NarrowCfg {
     static constexpr int A_INSTR = RA * 4;                                // per wave: 8 rows x 128 B each
 };
 
-template <int RA, int NB, bool CONV>
+template <int RA, int NB, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_nt_split_narrow_kernel(
     const float *__restrict__ A, int64_t lda, const unsigned short *__restrict__ Bp, float *C, int64_t ldc, int M, int N,
     int K, const float *__restrict__ bias, int relu, const float *addend, ConvGeom cg, int tiles_m, int tiles_n) {
@@ -1463,7 +1464,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_split_narrow_kernel(
     const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
     const unsigned lane16 = lane * 16u;
     int aoff[Cfg::A_INSTR];              // per-lane byte offset of its row's 16-B chunk (CONV: of pixel (oy*s-p, ox*s-p), may be < 0)
-    int ayx[CONV ? Cfg::A_INSTR : 1];    // CONV: (oy*s - p + 8) << 16 | (ox*s - p + 8)
+    int ayx[MODE == GATHER_CONV ? Cfg::A_INSTR : 1];    // CONV: (oy*s - p + 8) << 16 | (ox*s - p + 8)
     auto dma1 = [&](const char *sbase, unsigned voff, unsigned lds_byte) {
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -1478,12 +1479,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_split_narrow_kernel(
             const int p = wave * (RA * 32) + 8 * jj + (lane >> 3);
             const int ch = (lane & 7) ^ ((p >> 1) & 7);
             const int m = min(m0 + p, M - 1);
-            if (CONV) {
+            if (MODE == GATHER_CONV) {
                 const int ox = m % cg.Wo, t = m / cg.Wo;
                 const int oy = t % cg.Ho, b = t / cg.Ho;
                 const int iy0 = oy * cg.stride - cg.pad, ix0 = ox * cg.stride - cg.pad;
                 aoff[jj] = (((b * cg.H + iy0) * cg.W + ix0) * cg.C) * 4 + ch * 16;
                 ayx[jj] = ((iy0 + 8) << 16) | (ix0 + 8);
+            } else if (MODE == GATHER_STEM) {      // space-to-depth image Xs[b, Y, X, 12]: window of pixel (oy, ox) starts at (oy, ox)
+                const int ox = m % cg.Wo, t = m / cg.Wo;
+                const int oy = t % cg.Ho, b = t / cg.Ho;
+                aoff[jj] = ((b * cg.H + oy) * cg.W + ox) * 48;
             } else {
                 aoff[jj] = (int)((unsigned)m * (unsigned)(lda * 4)) + ch * 16;
             }
@@ -1494,12 +1499,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_split_narrow_kernel(
     auto cur_reset = [&](Cur &c) { c.kt = 0; c.ky = 0; c.kx = 0; c.c0 = 0; };
     auto cur_next = [&](Cur &c) {
         ++c.kt;
-        if (CONV) { c.c0 += BK; if (c.c0 == cg.C) { c.c0 = 0; if (++c.kx == cg.kw) { c.kx = 0; ++c.ky; } } }
+        if (MODE == GATHER_CONV) { c.c0 += BK; if (c.c0 == cg.C) { c.c0 = 0; if (++c.kx == cg.kw) { c.kx = 0; ++c.ky; } } }
     };
     auto dma = [&](int buf, const Cur &c, int tn) {
         const unsigned dst = lds_base + (unsigned)buf * Cfg::STAGE;
         const char *Ab = reinterpret_cast<const char *>(A);
-        if (CONV) {
+        if (MODE == GATHER_STEM) {
+            // K = 4 window rows x 48 contiguous floats (4 s2d pixels x 12 channels): 16-B chunk g of the K row lives in
+            // window row g / 12 at chunk g % 12; always inside the pre-padded image
+#pragma unroll
+            for (int jj = 0; jj < Cfg::A_INSTR; ++jj) {
+                const int p = wave * (RA * 32) + 8 * jj + (lane >> 3);
+                const int g = c.kt * 8 + ((lane & 7) ^ ((p >> 1) & 7));
+                const int qy = (g * 43) >> 9;                         // g / 12 for g < 48
+                dma1(Ab, (unsigned)(aoff[jj] + (qy * (3 * cg.W - 12) + g) * 16), dst + (wave * (RA * 32) + jj * 8) * (BK * 4));
+            }
+        } else if (MODE == GATHER_CONV) {
             const int soff = ((c.ky * cg.W + c.kx) * cg.C + c.c0) * 4;
 #pragma unroll
             for (int jj = 0; jj < Cfg::A_INSTR; ++jj) {
@@ -1665,14 +1680,14 @@ static int narrow_enabled() {
 
 // C[M,N] = act(A' W^T + bias + addend) with N <= 128 on the narrow kernels; A' = A[M,K] (geom == nullptr) or the implicit
 // im2col of the NHWC activation A described by *geom. `ws` as for launch_nt (the bf16 planes live behind the slab area).
-template <int RA, int NB, bool CONV>
+template <int RA, int NB, int MODE>
 static int launch_narrow_t(const float *A, int64_t lda, const float *W, int64_t ldw, float *C, int64_t ldc, int64_t M, int64_t N,
                            int64_t K, const float *bias, int relu, const float *addend, const ConvGeom &cg, void *ws,
                            hipStream_t st, const char *what) {
     using Cfg = NarrowCfg<RA, NB>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_split_narrow_kernel<RA, NB, CONV>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_split_narrow_kernel<RA, NB, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
         attr_set = true;
     }
@@ -1684,7 +1699,7 @@ static int launch_narrow_t(const float *A, int64_t lda, const float *W, int64_t 
     hipLaunchKernelGGL(split_planes_narrow_kernel<NB>, dim3(pgrid), dim3(256), 0, st, W, ldw, planes, (int)N, (int)K, tiles_n);
     int rc = check_launch(what);
     if (rc) return rc;
-    hipLaunchKernelGGL((gemm_nt_split_narrow_kernel<RA, NB, CONV>), dim3(PB_GRID), dim3(512), Cfg::SMEM, st, A, lda, planes, C, ldc,
+    hipLaunchKernelGGL((gemm_nt_split_narrow_kernel<RA, NB, MODE>), dim3(PB_GRID), dim3(512), Cfg::SMEM, st, A, lda, planes, C, ldc,
                        (int)M, (int)N, (int)K, bias, relu, addend, cg, tiles_m, tiles_n);
     return check_launch(what);
 }
@@ -1724,8 +1739,8 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
     if (use_big && use_split && !es.drop.thresh && !mask_src && ldb == K && (uint64_t)M * lda * 4 < (1ull << 32) &&
         narrow_ok(M, N, K, ldc, bias, addend, ws)) {
         const ConvGeom none{0, 0, 0, 0, 0, 0, 0, 0};
-        if (N <= 64) return launch_narrow_t<2, 2, false>(A, lda, B, ldb, C, ldc, M, N, K, bias, es.relu, addend, none, ws, st, what);
-        return launch_narrow_t<1, 4, false>(A, lda, B, ldb, C, ldc, M, N, K, bias, es.relu, addend, none, ws, st, what);
+        if (N <= 64) return launch_narrow_t<2, 2, GATHER_NONE>(A, lda, B, ldb, C, ldc, M, N, K, bias, es.relu, addend, none, ws, st, what);
+        return launch_narrow_t<1, 4, GATHER_NONE>(A, lda, B, ldb, C, ldc, M, N, K, bias, es.relu, addend, none, ws, st, what);
     }
     if (use_big && use_split && ws && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && (uint64_t)M * lda * 4 < (1ull << 32)) {
         // B is given as B[n, k] = Bsrc[n * bsn + k * bsk]; split it into pre-swizzled bf16 planes behind the slabs
@@ -1862,8 +1877,24 @@ extern "C" int toad_conv_nhwc_f32(const float *X, const float *Wf, const float *
     if (!narrow_ok(M, Cout, K, Cout, bias, residual, ws)) { set_error("%s: bias / residual must be 16-byte aligned", what); return TOAD_EALIGN; }
     const ConvGeom cg{H, W, Cin, Ho, Wo, kw, stride, pad};
     if (Cout <= 64)
-        return launch_narrow_t<2, 2, true>(X, 0, Wf, K, Y, Cout, M, Cout, K, bias, act == TOAD_ACT_RELU, residual, cg, ws, (hipStream_t)stream, what);
-    return launch_narrow_t<1, 4, true>(X, 0, Wf, K, Y, Cout, M, Cout, K, bias, act == TOAD_ACT_RELU, residual, cg, ws, (hipStream_t)stream, what);
+        return launch_narrow_t<2, 2, GATHER_CONV>(X, 0, Wf, K, Y, Cout, M, Cout, K, bias, act == TOAD_ACT_RELU, residual, cg, ws, (hipStream_t)stream, what);
+    return launch_narrow_t<1, 4, GATHER_CONV>(X, 0, Wf, K, Y, Cout, M, Cout, K, bias, act == TOAD_ACT_RELU, residual, cg, ws, (hipStream_t)stream, what);
+}
+
+extern "C" int toad_stem_conv_s2d_f32(const float *Xs, const float *Wf, const float *bias, float *Y, int B, int Ho, int Wo, int act,
+                                      void *ws, size_t ws_bytes, void *stream) {
+    const char *what = "toad_stem_conv_s2d_f32";
+    if (!Xs || !Wf || !Y || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (act != TOAD_ACT_NONE && act != TOAD_ACT_RELU) { set_error("%s: bad act %d", what, act); return TOAD_EINVAL; }
+    if (B <= 0 || Ho <= 0 || Wo <= 0) { set_error("%s: bad geometry", what); return TOAD_ESHAPE; }
+    const int Hs = Ho + 3, Ws = Wo + 3;
+    const int64_t M = (int64_t)B * Ho * Wo;
+    if ((uint64_t)B * Hs * Ws * 48 >= (1ull << 31) || M >= (1ll << 31)) { set_error("%s: batch too large for 32-bit offsets (split it)", what); return TOAD_ESHAPE; }
+    if (!aligned16(Xs) || !aligned16(Wf) || !aligned16(Y)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (int rc = check_ws(ws, ws_bytes, M, 64, 192, what)) return rc;
+    if (!narrow_ok(M, 64, 192, 64, bias, nullptr, ws)) { set_error("%s: bias must be 16-byte aligned", what); return TOAD_EALIGN; }
+    const ConvGeom cg{Hs, Ws, 12, Ho, Wo, 0, 0, 0};
+    return launch_narrow_t<2, 2, GATHER_STEM>(Xs, 0, Wf, 192, Y, 64, M, 64, 192, bias, act == TOAD_ACT_RELU, nullptr, cg, ws, (hipStream_t)stream, what);
 }
 
 extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend, const float *relu_src,

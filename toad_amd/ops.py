@@ -375,6 +375,22 @@ def im2col_stem_nchw(x: torch.Tensor) -> torch.Tensor:
     return cols
 
 
+def stem_conv(x: torch.Tensor, wf: torch.Tensor, b, act: int) -> torch.Tensor:
+    """7x7/2 pad-3 stem on NCHW tiles via the space-to-depth image: x [B,3,H,W], wf [64,192] -> [B,Ho,Wo,64] NHWC."""
+    _chk(x, "x"); _chk(wf, "wf"); _chk(b, "b", allow_none=True)
+    bb, c, h, w = x.shape
+    if c != 3 or tuple(wf.shape) != (64, 192):
+        raise ValueError("stem_conv: expected [B,3,H,W] tiles and a [64,192] space-to-depth weight")
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    xs = torch.empty((bb, ho + 3, wo + 3, 12), dtype=torch.float32, device=x.device)
+    y = torch.empty((bb, ho, wo, 64), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.toad_stem_s2d_nchw_f32(_p(x), _p(xs), bb, h, w, _stream()), "toad_stem_s2d_nchw_f32")
+    ws = _ws(lib.toad_linear_ws_bytes(bb * ho * wo, 64, 192), x.device)
+    _lib.check(lib.toad_stem_conv_s2d_f32(_p(xs), _p(wf), _p(b), _p(y), bb, ho, wo, act, _p(ws), ws.numel(), _stream()), "toad_stem_conv_s2d_f32")
+    return y
+
+
 def maxpool3x3s2_nhwc(x: torch.Tensor) -> torch.Tensor:
     _chk(x, "x")
     b, h, w, c = x.shape

@@ -24,7 +24,7 @@ from . import _lib
 
 __all__ = ["Bottleneck_Baseline", "ResNet_Baseline", "resnet50_baseline"]
 
-STEM_K = 160            # 3*7*7 = 147 columns, zero-padded to the GEMM's 32-wide k-step
+STEM_K = 192            # 4 x 4 space-to-depth taps x 12 channels (147 real taps + zero slots)
 MAX_TILES_PER_CALL = 256
 
 
@@ -54,9 +54,10 @@ def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d, stem: bool):
     scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
     shift = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
     w = w * scale.view(-1, 1, 1, 1)
-    if stem:                                            # (c, ky, kx) order, padded to STEM_K columns
-        w2 = torch.zeros(w.shape[0], STEM_K, dtype=torch.float64, device=w.device)
-        w2[:, :w[0].numel()] = w.reshape(w.shape[0], -1)
+    if stem:                                            # space-to-depth operand of toad_stem_conv_s2d_f32: [64, 4(qy), 4(qx), 2(ry), 2(rx), 3(c)]
+        w8 = torch.zeros(w.shape[0], 3, 8, 8, dtype=torch.float64, device=w.device)
+        w8[:, :, 1:, 1:] = w                            # slot (2q + r) holds tap 2q + r - 1; slot 0 (tap -1) stays zero
+        w2 = w8.view(w.shape[0], 3, 4, 2, 4, 2).permute(0, 2, 4, 3, 5, 1).reshape(w.shape[0], STEM_K)
     else:                                               # (ky, kx, c) order = the NHWC gather's column order
         w2 = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
     return w2.float().contiguous(), shift.float().contiguous()
