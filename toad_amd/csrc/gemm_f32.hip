@@ -1756,10 +1756,10 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
                            (int)N, (int)K, bias, es, addend, mask_src, (float *)ws, tiles_m, tiles_n);
         rc = check_launch(what);
         if (rc) return rc;
-        bool any_rem = false;
-        for (int x = 0; x < kNumXCD; ++x) any_rem |= nt_plan(x, tiles_m, tiles_n, (int)(K / BK)).rem > 0;
-        if (any_rem) {
-            hipLaunchKernelGGL(nt_fixup_kernel, dim3(64, PB_BLOCKS_PER_XCD - 1, kNumXCD), dim3(256), 0, st, (const float *)ws, C,
+        int max_rem = 0;                                   // fix-up grid: only as many tile rows as some XCD has remainder tiles
+        for (int x = 0; x < kNumXCD; ++x) { const int r = nt_plan(x, tiles_m, tiles_n, (int)(K / BK)).rem; if (r > max_rem) max_rem = r; }
+        if (max_rem > 0) {
+            hipLaunchKernelGGL(nt_fixup_kernel, dim3(64, max_rem, kNumXCD), dim3(256), 0, st, (const float *)ws, C,
                                ldc, (int)M, (int)N, (int)K, bias, es, addend, mask_src, tiles_m, tiles_n);
             rc = check_launch(what);
         }
@@ -1772,10 +1772,10 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
                            (int)N, (int)K, bias, es, addend, mask_src, (float *)ws, tiles_m, tiles_n);
         int rc = check_launch(what);
         if (rc) return rc;
-        bool any_rem = false;
-        for (int x = 0; x < kNumXCD; ++x) any_rem |= nt_plan(x, tiles_m, tiles_n, (int)(K / BK)).rem > 0;
-        if (any_rem) {
-            hipLaunchKernelGGL(nt_fixup_kernel, dim3(64, PB_BLOCKS_PER_XCD - 1, kNumXCD), dim3(256), 0, st, (const float *)ws, C,
+        int max_rem = 0;                                   // fix-up grid: only as many tile rows as some XCD has remainder tiles
+        for (int x = 0; x < kNumXCD; ++x) { const int r = nt_plan(x, tiles_m, tiles_n, (int)(K / BK)).rem; if (r > max_rem) max_rem = r; }
+        if (max_rem > 0) {
+            hipLaunchKernelGGL(nt_fixup_kernel, dim3(64, max_rem, kNumXCD), dim3(256), 0, st, (const float *)ws, C,
                                ldc, (int)M, (int)N, (int)K, bias, es, addend, mask_src, tiles_m, tiles_n);
             rc = check_launch(what);
         }
