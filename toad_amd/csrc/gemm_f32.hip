@@ -1594,6 +1594,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_split_narrow_kernel(
     };
 
     typedef float fvec __attribute__((ext_vector_type(NB)));
+    constexpr int EG = 16;               // residual rows loaded back to back (clamped addresses, no branch in between)
     auto epilogue = [&](int m0, int n0) {
         int lic = NB * li, hi4 = 4 * hi;
         asm volatile("" : "+v"(lic), "+v"(hi4));
@@ -1604,8 +1605,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_split_narrow_kernel(
         for (int e = 0; e < NB; ++e) bv[e] = 0.f;
         if (bias && cok) bv = *reinterpret_cast<const fvec *>(bias + col);
         asm volatile("" : "+v"(bv));
+        const bool has_add = addend != nullptr;
+        const int colc = cok ? col : 0;
 #pragma unroll
         for (int a = 0; a < RA; ++a) {
+            fvec av[EG];
+#pragma unroll
+            for (int g = 0; g < EG; ++g) {
+                const int rowc = min(m0 + wave * (RA * 32) + a * 32 + (g & 3) + 8 * (g >> 2) + hi4, M - 1);
+#pragma unroll
+                for (int e = 0; e < NB; ++e) av[g][e] = 0.f;
+                if (has_add) av[g] = *reinterpret_cast<const fvec *>(addend + (int64_t)rowc * ldc + colc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wave * (RA * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + hi4;
@@ -1613,17 +1625,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_split_narrow_kernel(
                     fvec v;
 #pragma unroll
                     for (int e = 0; e < NB; ++e) v[e] = acc[a][e][r];
-                    const int64_t off = (int64_t)row * ldc + col;
                     v += bv;
-                    if (addend) v += *reinterpret_cast<const fvec *>(addend + off);
+                    v += av[r];
                     if (relu) {
 #pragma unroll
                         for (int e = 0; e < NB; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     }
-                    __builtin_nontemporal_store(v, reinterpret_cast<fvec *>(C + off));
+                    __builtin_nontemporal_store(v, reinterpret_cast<fvec *>(C + (int64_t)row * ldc + col));
                 }
-                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -1704,8 +1715,16 @@ static int launch_narrow_t(const float *A, int64_t lda, const float *W, int64_t 
     return check_launch(what);
 }
 
+static int narrow_res_kmax() {
+    static int v = -1;
+    // measured (tools/gemm_shape_bench.py, same box): M=262144 K=64 N=256 +residual 170 -> 133 us on the 256x128 narrow tiles
+    // (16 residual rows in flight per wave); K=128 equal, K=256 slower (A is re-split per 128-column tile) -> default 64
+    if (v < 0) { const char *e = getenv("TOAD_NARROW_RES_KMAX"); v = e ? atoi(e) : 64; }
+    return v;
+}
 static bool narrow_ok(int64_t M, int64_t N, int64_t K, int64_t ldc, const float *bias, const float *addend, void *ws) {
-    return narrow_enabled() && ws && N <= 128 && N % 4 == 0 && K % BK == 0 && ldc % 4 == 0 && M < (1ll << 31) &&
+    const bool wide_ok = addend && K <= narrow_res_kmax();       // residual GEMMs with a short reduction: epilogue-bound, see DESIGN 10
+    return narrow_enabled() && ws && (N <= 128 || wide_ok) && N % 4 == 0 && K % BK == 0 && ldc % 4 == 0 && M < (1ll << 31) &&
            (!bias || aligned16(bias)) && (!addend || aligned16(addend));
 }
 
