@@ -705,6 +705,45 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_split_big_kernel(
         if (bias && cok) bv = ld4(bias + ucol + li4);
         asm volatile("" : "+v"(bv));
         float *slab = slabs + (int64_t)blockIdx.x * PB * PB + wn * 128;
+        if (!partial && addend && !mask_src) {
+            // residual epilogue (convolution + skip connection): the per-row `if (in range) { load; add; store }` below makes
+            // every row a dependent HBM round trip; here 8 rows of the residual are loaded back to back from CLAMPED
+            // addresses (no branch in between), then finished and stored. (With a mask as well - the dgrads - 8 rows
+            // of two operands do not fit the register budget: those keep the loop below.)
+            const int colc = cok ? ucol + li4 : 0;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 8) {
+                    f32x4 av[8];
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const int r = r0 + g;
+                        const int rowc = min(m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + hi4, M - 1);
+                        av[g] = ld4(addend + (int64_t)rowc * ldc + colc);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const int r = r0 + g;
+                        const int urow = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2);
+                        if (cok && (m0 + urow + hi4) < M) {
+                            f32x4 v = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+                            v += bv; v += av[g];
+                            if (es.relu) { v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f; v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f; }
+                            if (es.drop.thresh) {
+                                const uint64_t fi = (uint64_t)(m0 + urow + hi4) * (uint64_t)N + (uint64_t)(ucol + li4);
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) v[k] *= drop_keep(fi + k, es.drop);
+                            }
+                            st4s(C + (int64_t)(m0 + urow) * ldc + ucol + voff, v);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
 #pragma unroll
