@@ -283,6 +283,23 @@ __device__ __forceinline__ f32x4 apply_epilogue(f32x4 v, const EpiScalars &e, co
     return v;
 }
 
+// same, with the addend / mask vectors already loaded
+__device__ __forceinline__ f32x4 apply_epilogue_v(f32x4 v, const EpiScalars &e, f32x4 av, bool has_add, f32x4 mv, bool has_msk, f32x4 bv,
+                                                  uint64_t flat_idx) {
+    v += bv;
+    if (has_add) v += av;
+    if (e.relu) { v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f; v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f; }
+    if (e.drop.thresh) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= drop_keep(flat_idx + k, e.drop);
+    }
+    if (has_msk) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = mv[k] > 0.f ? v[k] * e.mask_scale : 0.f;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(512, 2) void gemm_nt_f32_big_kernel(
     const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
     float *C, int64_t ldc, int M, int N, int K, const float *__restrict__ bias, EpiScalars es, const float *addend,
@@ -737,6 +754,40 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_split_big_kernel(
                                 for (int k = 0; k < 4; ++k) v[k] *= drop_keep(fi + k, es.drop);
                             }
                             st4s(C + (int64_t)(m0 + urow) * ldc + ucol + voff, v);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            return;
+        }
+        if (!partial && mask_src) {
+            // dgrad epilogue (mask, optionally addend): 4 rows of both operands in flight, clamped addresses, no branch between loads
+            const bool has_add = addend != nullptr;
+            const int colc = cok ? ucol + li4 : 0;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 4) {
+                    f32x4 av[4], mv[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int r = r0 + g;
+                        const int rowc = min(m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + hi4, M - 1);
+                        const int64_t off = (int64_t)rowc * ldc + colc;
+                        mv[g] = ld4(mask_src + off);
+                        av[g] = has_add ? ld4(addend + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int r = r0 + g;
+                        const int urow = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2);
+                        if (cok && (m0 + urow + hi4) < M) {
+                            f32x4 v = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+                            st4s(C + (int64_t)(m0 + urow) * ldc + ucol + voff,
+                                 apply_epilogue_v(v, es, av[g], has_add, mv[g], true, bv,
+                                                  (uint64_t)(m0 + urow + hi4) * (uint64_t)N + (uint64_t)(ucol + li4)));
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
