@@ -37,6 +37,34 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.toad_linear_wgrad_ws_bytes(100000, 512, 1024) >= 512 * 1024 * 4
 
 
+def test_extractor_entry_points_validate_arguments_without_a_gpu():
+    """Every new conv / extractor entry point rejects bad arguments before touching the device, with a message."""
+    import ctypes
+    from toad_amd import _lib
+    lib = _lib.load()
+    one = ctypes.c_void_p(16)                  # a non-null, 16-byte aligned fake pointer: argument checks come first
+    err = lambda: lib.toad_last_error().decode()
+    assert lib.toad_conv_nhwc_f32(None, None, None, None, None, 1, 8, 8, 64, 3, 3, 1, 1, 64, 1, None, 0, None) == -1 and "null pointer" in err()
+    assert lib.toad_conv_nhwc_f32(one, one, None, None, one, 1, 8, 8, 48, 3, 3, 1, 1, 64, 1, one, 1 << 30, None) == -2 and "multiple of 32" in err()
+    assert lib.toad_conv_nhwc_f32(one, one, None, None, one, 1, 8, 8, 64, 3, 3, 1, 1, 256, 1, one, 1 << 30, None) == -2 and "Cout <= 128" in err()
+    assert lib.toad_conv_nhwc_f32(one, one, None, None, one, 1, 2, 2, 64, 5, 5, 1, 0, 64, 1, one, 1 << 30, None) == -2 and "empty output" in err()
+    assert lib.toad_conv_nhwc_f32(one, one, None, None, one, 1, 8, 8, 64, 3, 3, 1, 1, 64, 7, one, 1 << 30, None) == -1 and "bad act" in err()
+    assert lib.toad_conv_nhwc_f32(one, one, None, None, one, 1, 8, 8, 64, 3, 3, 1, 1, 64, 1, one, 16, None) == -3 and "workspace too small" in err()
+    assert lib.toad_im2col_nhwc_f32(one, one, 1, 8, 8, 6, 3, 3, 1, 1, None) == -2 and "multiple of 4" in err()
+    assert lib.toad_im2col_nhwc_f32(ctypes.c_void_p(4), one, 1, 8, 8, 8, 3, 3, 1, 1, None) == -4 and "aligned" in err()
+    assert lib.toad_maxpool3x3s2_nhwc_f32(one, None, 1, 8, 8, 64, None) == -1
+    assert lib.toad_avgpool_nhwc_f32(one, one, 70000, 4, 64, None) == -2
+    assert lib.toad_stem_s2d_nchw_f32(one, one, 0, 8, 8, None) == -2
+    assert lib.toad_stem_conv_s2d_f32(one, one, None, one, 1, 4, 4, 1, one, 16, None) == -3
+    assert lib.toad_linear_act_res_fwd_f32(one, one, None, ctypes.c_void_p(20), one, 8, 32, 64, 1, None, 0, None) == -2 and "residual" in err()
+    assert lib.toad_resnet50_trunc_ws_bytes(0, 256, 256) == 0 and lib.toad_resnet50_trunc_ws_bytes(4, 256, 256) > 4 * 20e6
+    w = (ctypes.c_void_p * 43)(*([16] * 43))
+    assert lib.toad_resnet50_trunc_fwd_f32(one, w, w, one, 2, 64, 64, one, 1024, None) == -3 and "workspace too small" in err()
+    w[7] = None
+    big = lib.toad_resnet50_trunc_ws_bytes(2, 64, 64)
+    assert lib.toad_resnet50_trunc_fwd_f32(one, w, w, one, 2, 64, 64, one, big, None) == -1 and "slot 7" in err()
+
+
 def test_constructor_and_state_dict_match_reference(golden):
     from toad_amd import TOAD_fc_mtl_concat
     def plain(fn):      # "(self, gate=True, ...)" without annotations
