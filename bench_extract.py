@@ -1,6 +1,6 @@
 """bench_extract.py — BASELINE config 5: tiles -> ResNet-50-trunc extractor -> on-the-fly bag -> attention-MIL step.
 
-    python bench_extract.py --gpus 1 --steps 5 --warmup 2 [--tiles 2048] [--chunk 128]
+    python bench_extract.py --gpus 1 --steps 5 --warmup 2 [--tiles 2048] [--chunk 512]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench_extract.py --gpus N ...
 
@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tiles", type=int, default=2048, help="tiles (= patches) per slide")
-    ap.add_argument("--chunk", type=int, default=128, help="tiles per extractor call")
+    ap.add_argument("--chunk", type=int, default=512, help="tiles per extractor call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -25,7 +25,7 @@ from . import _lib
 __all__ = ["Bottleneck_Baseline", "ResNet_Baseline", "resnet50_baseline"]
 
 STEM_K = 192            # 4 x 4 space-to-depth taps x 12 channels (147 real taps + zero slots)
-MAX_TILES_PER_CALL = 256
+MAX_TILES_PER_CALL = 512     # 32-bit byte offsets inside the kernels: B*64*64*128*4 < 2^31 (layer2.0 conv2 input)
 
 
 class Bottleneck_Baseline(nn.Module):
