@@ -170,7 +170,8 @@ int toad_linear_act_res_fwd_f32(const float *X, const float *W, const float *bia
  *   Y[b,oy,ox,:] = act(sum_{ky,kx,c} X[b, oy*stride-pad+ky, ox*stride-pad+kx, c] * Wf[:, (ky*kw+kx)*Cin + c] + bias (+ residual))
  * = nn.Conv2d(Cin, Cout, (kh,kw), stride, pad, bias=False) + folded BN [+ skip] + ReLU (resnet_custom.py:26-27,42-44).
  * The gather happens inside the GEMM's LDS-DMA (per k-stage tap offset, zero fill outside the image).
- * Needs Cin % 32 == 0 and Cout <= 128 (the narrow-tile kernels); wider layers use toad_im2col_nhwc_f32 + the GEMM. */
+ * Needs Cin % 32 == 0 and Cout <= 512 (the narrow-tile kernels, 64 / 128 output columns per tile: every further 128 columns
+ * gather and split the activation again, so wide layers are usually faster through toad_im2col_nhwc_f32 + the GEMM). */
 int toad_conv_nhwc_f32(const float *X, const float *Wf, const float *bias, const float *residual, float *Y,
                        int B, int H, int W, int Cin, int kh, int kw, int stride, int pad, int Cout, int act,
                        void *ws, size_t ws_bytes, void *stream);

@@ -46,7 +46,7 @@ def test_extractor_entry_points_validate_arguments_without_a_gpu():
     err = lambda: lib.toad_last_error().decode()
     assert lib.toad_conv_nhwc_f32(None, None, None, None, None, 1, 8, 8, 64, 3, 3, 1, 1, 64, 1, None, 0, None) == -1 and "null pointer" in err()
     assert lib.toad_conv_nhwc_f32(one, one, None, None, one, 1, 8, 8, 48, 3, 3, 1, 1, 64, 1, one, 1 << 30, None) == -2 and "multiple of 32" in err()
-    assert lib.toad_conv_nhwc_f32(one, one, None, None, one, 1, 8, 8, 64, 3, 3, 1, 1, 256, 1, one, 1 << 30, None) == -2 and "Cout <= 128" in err()
+    assert lib.toad_conv_nhwc_f32(one, one, None, None, one, 1, 8, 8, 64, 3, 3, 1, 1, 1024, 1, one, 1 << 30, None) == -2 and "Cout <= 512" in err()
     assert lib.toad_conv_nhwc_f32(one, one, None, None, one, 1, 2, 2, 64, 5, 5, 1, 0, 64, 1, one, 1 << 30, None) == -2 and "empty output" in err()
     assert lib.toad_conv_nhwc_f32(one, one, None, None, one, 1, 8, 8, 64, 3, 3, 1, 1, 64, 7, one, 1 << 30, None) == -1 and "bad act" in err()
     assert lib.toad_conv_nhwc_f32(one, one, None, None, one, 1, 8, 8, 64, 3, 3, 1, 1, 64, 1, one, 16, None) == -3 and "workspace too small" in err()

@@ -146,6 +146,8 @@ def test_linear_act_res_matches_fp64(cuda, m, k, n, res, act):
     (5, 10, 12, 96, 100, 3, 1, 1, True),      # Cin not a power of two, ragged Cout
     (1, 1, 1, 64, 64, 3, 1, 1, False),        # a single pixel: 8 of 9 taps are padding
     (2, 9, 9, 64, 128, 5, 2, 2, False),       # 5x5
+    (2, 16, 16, 256, 256, 3, 1, 1, False),    # layer3 conv2: two 128-column tiles per row tile
+    (1, 12, 12, 64, 300, 3, 1, 1, True),      # three column tiles, the last one ragged
 ])
 def test_implicit_conv_matches_fp64(cuda, b, h, w, cin, cout, k, s, p, res):
     from toad_amd import ops
@@ -166,7 +168,10 @@ def test_implicit_conv_matches_fp64(cuda, b, h, w, cin, cout, k, s, p, res):
     # the implicit gather and the explicit im2col + GEMM are the same arithmetic in the same order
     cols = ops.im2col_nhwc(x.to(cuda), k, k, s, p)
     y2 = ops.linear_act_res_fwd(cols, wf.to(cuda), bias.to(cuda), None if r is None else r.to(cuda).view(-1, cout), 1).cpu()
-    assert torch.equal(y.view(-1, cout), y2)
+    if cout <= 128:
+        assert torch.equal(y.view(-1, cout), y2)
+    else:       # wider layers: the explicit path runs on the 256x256 kernel (other tile shape, K-split) - same values to roundoff
+        assert (y.view(-1, cout) - y2).abs().max().item() <= 2e-5
 
 
 @pytest.mark.gpu

@@ -296,7 +296,11 @@ extern "C" int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float 
             TOAD_TRY(toad_linear_act_res_fwd_f32(x, weights[ci], biases[ci], nullptr, t1, Mi, inpl, pl, TOAD_ACT_RELU, gws, gcap, st));
             // conv2 3x3 stride s + BN + ReLU (:42-44)
             float *t2 = other(x, t1, nullptr);
-            if (pl <= 128 && implicit_conv_enabled()) {            // gather inside the GEMM's LDS-DMA: no cols buffer
+            // gather inside the GEMM's LDS-DMA, no cols buffer: always for the narrow layers; for 256 output channels (two
+            // 128-column tiles per 256 rows, A gathered and split twice) only when there are enough tiles to fill the chip
+            // twice over - otherwise im2col + the 256x256 kernel with its K-split is faster (measured at B = 64 vs 512)
+            const bool implicit = implicit_conv_enabled() && (pl <= 128 || (pl <= 256 && (Mo / 256) * ((pl + 127) / 128) >= 512));
+            if (implicit) {
                 TOAD_TRY(toad_conv_nhwc_f32(t1, weights[ci + 1], biases[ci + 1], nullptr, t2, B, h, w, pl, 3, 3, s, 1, pl, TOAD_ACT_RELU, gws, gcap, st));
             } else {
                 TOAD_TRY(toad_im2col_nhwc_f32(t1, cols, B, h, w, pl, 3, 3, s, 1, st));

@@ -1976,14 +1976,14 @@ extern "C" int toad_conv_nhwc_f32(const float *X, const float *Wf, const float *
     if (act != TOAD_ACT_NONE && act != TOAD_ACT_RELU) { set_error("%s: bad act %d", what, act); return TOAD_EINVAL; }
     if (B <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0 || pad > 8 || H + 8 >= 32768 || W + 8 >= 32768) { set_error("%s: bad geometry", what); return TOAD_ESHAPE; }
     if (Cin <= 0 || Cin % BK != 0) { set_error("%s: Cin must be a multiple of %d (use toad_im2col_nhwc_f32 + toad_linear_act_res_fwd_f32 otherwise)", what, BK); return TOAD_ESHAPE; }
-    if (Cout <= 0 || Cout > 128 || Cout % 4 != 0) { set_error("%s: implicit path needs Cout <= 128, a multiple of 4 (use im2col + linear for wider layers)", what); return TOAD_ESHAPE; }
+    if (Cout <= 0 || Cout > 512 || Cout % 4 != 0) { set_error("%s: implicit path needs Cout <= 512, a multiple of 4 (use im2col + linear for wider layers)", what); return TOAD_ESHAPE; }
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     if (Ho < 1 || Wo < 1) { set_error("%s: empty output", what); return TOAD_ESHAPE; }
     const int64_t M = (int64_t)B * Ho * Wo, K = (int64_t)kh * kw * Cin;
     if ((uint64_t)B * H * W * Cin * 4 >= (1ull << 31) || M >= (1ll << 31)) { set_error("%s: activation too large for 32-bit offsets (split the batch)", what); return TOAD_ESHAPE; }
     if (!aligned16(X) || !aligned16(Wf) || !aligned16(Y)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
     if (int rc = check_ws(ws, ws_bytes, M, Cout, K, what)) return rc;
-    if (!narrow_ok(M, Cout, K, Cout, bias, residual, ws)) { set_error("%s: bias / residual must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (!narrow_ok(M, Cout <= 128 ? Cout : 128, K, Cout, bias, residual, ws)) { set_error("%s: bias / residual must be 16-byte aligned", what); return TOAD_EALIGN; }
     const ConvGeom cg{H, W, Cin, Ho, Wo, kw, stride, pad};
     if (Cout <= 64)
         return launch_narrow_t<2, 2, GATHER_CONV>(X, 0, Wf, K, Y, Cout, M, Cout, K, bias, act == TOAD_ACT_RELU, residual, cg, ws, (hipStream_t)stream, what);
