@@ -7,7 +7,7 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 g = [((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, r['Kernel_Name']) for r in rows
      if 'gemm_nt_split' in r['Kernel_Name']]
 last = g[-43:]
-order = [("stem", B * 128 * 128, 160, 64)]
+order = [("stem", B * 128 * 128, 147, 64)]   # algorithmic K (the kernel runs the 192-column space-to-depth operand)
 inpl, hh = 64, 64
 for li, (pl, blocks, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2)), 1):
     for b in range(blocks):
