@@ -211,6 +211,39 @@ def test_extractor_matches_reference_features(cuda, rg):
 
 
 @pytest.mark.gpu
+def test_full_size_properties(cuda):
+    """BASELINE config 5 sizes (256x256 tiles, 160 per call - enough tiles to switch the 256-channel 3x3 to the implicit path
+    for part of the chunks): size-independent properties instead of an oracle run.
+      * permutation equivariance: features of permuted tiles = permuted features, to roundoff (not bitwise: which 256-row
+        tiles of a GEMM are K-split into slabs depends on their position in the launch, so a row's partial sums may be
+        grouped differently after the permutation);
+      * chunking: 160 tiles at once vs 5 x 32 agree to roundoff (different kernels serve the 256-channel 3x3 at the two batch sizes);
+      * determinism: two runs are bitwise equal."""
+    from toad_amd.resnet_custom import resnet50_baseline
+    import toad_amd.resnet_custom as rc
+    model = resnet50_baseline(); model.load_state_dict(ro.make_params(31)); model.relocate(); model.eval()
+    g = torch.Generator(device=cuda).manual_seed(5)
+    x = torch.randn(160, 3, 256, 256, device=cuda, generator=g)
+    perm = torch.randperm(160, generator=torch.Generator().manual_seed(1)).to(cuda)
+    with torch.no_grad():
+        f = model(x)
+        assert torch.equal(f, model(x))
+        fp = model(x[perm])
+        old = rc.MAX_TILES_PER_CALL
+        try:
+            rc.MAX_TILES_PER_CALL = 32
+            f32 = model(x)
+        finally:
+            rc.MAX_TILES_PER_CALL = old
+    scale = f.abs().max().item()
+    assert torch.isfinite(f).all() and (f - f32).abs().max().item() <= 1e-5 * max(scale, 1.0)
+    assert (fp - f[perm]).abs().max().item() <= 1e-5 * max(scale, 1.0)
+    # two tiles checked against the CPU oracle at full size
+    ref = ro.forward(ro.make_params(31), x[:2].cpu())
+    assert (f[:2].cpu() - ref).abs().max().item() <= 1e-4
+
+
+@pytest.mark.gpu
 def test_tiles_to_bag_to_mil_forward(cuda):
     """BASELINE config 5 end to end at toy size: tiles -> extractor -> bag [N,1024] -> MIL forward, against the oracles."""
     from oracle import toad_oracle as orc
