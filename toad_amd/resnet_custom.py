@@ -29,17 +29,16 @@ MAX_TILES_PER_CALL = 512     # 32-bit byte offsets inside the kernels: B*64*64*1
 
 
 class Bottleneck_Baseline(nn.Module):
-    """Parameter container with the reference's layout (resnet_custom.py:19-33)."""
+    """Parameter container of one bottleneck block, children named and shaped as in the reference (resnet_custom.py:19-33):
+    conv1 1x1 -> bn1 -> conv2 3x3 (carries the stride) -> bn2 -> conv3 1x1 (x4 channels) -> bn3, optional downsample."""
     expansion = 4
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.conv3 = nn.Conv2d(planes, planes * self.expansion, kernel_size=1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        out = planes * self.expansion
+        for i, (cin, cout, k, s) in enumerate(((inplanes, planes, 1, 1), (planes, planes, 3, stride), (planes, out, 1, 1)), start=1):
+            self.add_module(f"conv{i}", nn.Conv2d(cin, cout, kernel_size=k, stride=s, padding=k // 2, bias=False))
+            self.add_module(f"bn{i}", nn.BatchNorm2d(cout))
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
@@ -87,16 +86,14 @@ class ResNet_Baseline(nn.Module):
         self._ws: Optional[torch.Tensor] = None
 
     def _make_layer(self, block, planes, blocks, stride=1):
-        downsample = None
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            downsample = nn.Sequential(
-                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
-                nn.BatchNorm2d(planes * block.expansion))
-        layers = [block(self.inplanes, planes, stride, downsample)]
-        self.inplanes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes))
-        return nn.Sequential(*layers)
+        """`blocks` bottlenecks; the first one carries the stride and, when the shape changes, the 1x1 projection of the skip."""
+        width = planes * block.expansion
+        proj = None
+        if stride != 1 or self.inplanes != width:
+            proj = nn.Sequential(nn.Conv2d(self.inplanes, width, kernel_size=1, stride=stride, bias=False), nn.BatchNorm2d(width))
+        stack = [block(self.inplanes, planes, stride, proj)] + [block(width, planes) for _ in range(blocks - 1)]
+        self.inplanes = width
+        return nn.Sequential(*stack)
 
     # ---- folded-weight cache ------------------------------------------------------------------------------------
     def refold(self) -> None:
