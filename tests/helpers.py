@@ -21,6 +21,8 @@ def case_inputs(golden, name):
 def strided_sample(t, k=64):
     flat = t.detach().reshape(-1).cpu()
     n = flat.numel()
+    if n == 0:
+        return np.zeros((0,), dtype=np.float32)
     idx = (np.arange(k, dtype=np.int64) * max(n // k, 1)) % n
     return flat[torch.from_numpy(idx)].numpy().astype(np.float32)
 

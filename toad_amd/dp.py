@@ -52,6 +52,14 @@ def hip_slide_grad(model, grads: Dict[str, torch.Tensor], slide: Slide, beta: fl
     bag, sex, label, site = slide
     w = {k: v.detach() for k, v in model._weights().items()}
     drop_p, seed = _draw_dropout(model._dropout and model.training)
+    if bag.shape[0] == 0:
+        # empty bag (reference semantics: zero pooled features, the heads still see `sex`): per-op path, no trunk launches
+        from . import functional as F_
+        sexf = sex.to(torch.float32).reshape(1)
+        outs, sv = F_.mil_forward(w, bag, sexf)
+        loss, dl, ds = ops.mtl_ce_fwd_bwd(outs["logits"], outs["site_logits"], label, site, w_cls * scale, w_site * scale)
+        F_.mil_backward(w, sv, dl, ds, grads=grads, beta=beta)
+        return loss
     loss, _, _ = ops.mil_step(w, grads, beta, bag, sex.to(torch.float32).reshape(1), label, site,
                               w_cls * scale, w_site * scale, drop_p, seed)      # one C-ABI call per slide
     return loss

@@ -65,10 +65,19 @@ def trunk_scores(w: Dict[str, torch.Tensor], x: torch.Tensor, drop_p: float = 0.
 def mil_forward(w: Dict[str, torch.Tensor], x: torch.Tensor, sex: torch.Tensor, drop_p: float = 0.0, seed: int = 0):
     """TOAD_fc_mtl_concat.forward (models/model_toad.py:90-116) without the python dict.
     ``drop_p`` > 0 = training with dropout=True; ``seed`` selects the masks (recomputed in backward)."""
-    h1, h, p = trunk_scores(w, x, drop_p, seed)
     d = w["wa"].shape[0]
-    _, _, sa, sb = drop_seeds(seed)
-    a_raw, m, stats = ops.gated_pool_fwd(p, d, h, w["wc"], w["bc"], drop_p, sa, sb)
+    if x.shape[0] == 0:
+        # empty bag: the reference's softmax over zero patches followed by mm([T,0],[0,L]) gives M = 0 and the heads still
+        # run on (0, sex) (model_toad.py:96-107); there is no trunk / pooling work to launch
+        l, t = w["w2"].shape[0], w["wc"].shape[0]
+        e = lambda c: torch.empty((0, c), dtype=torch.float32, device=x.device)
+        h1, h, p, a_raw = e(w["w1"].shape[0]), e(l), e(2 * d), e(t)
+        m = torch.zeros((t, l), dtype=torch.float32, device=x.device)
+        stats = torch.zeros((t, 2), dtype=torch.float32, device=x.device)
+    else:
+        h1, h, p = trunk_scores(w, x, drop_p, seed)
+        _, _, sa, sb = drop_seeds(seed)
+        a_raw, m, stats = ops.gated_pool_fwd(p, d, h, w["wc"], w["bc"], drop_p, sa, sb)
     mcat, logits, y_prob, y_hat, site_logits, site_prob, site_hat = ops.heads_fwd(
         m, sex, w["wcls"], w["bcls"], w["wsite"], w["bsite"])
     saved = Saved(x=x, h1=h1, h=h, p=p, a_raw=a_raw, stats=stats, m=m, mcat=mcat, drop_p=drop_p, seed=seed)
@@ -79,6 +88,8 @@ def mil_forward(w: Dict[str, torch.Tensor], x: torch.Tensor, sex: torch.Tensor, 
 
 def attention_scores(w: Dict[str, torch.Tensor], x: torch.Tensor, drop_p: float = 0.0, seed: int = 0) -> torch.Tensor:
     """attention_only path (models/model_toad.py:93-94): A_raw [N,T] without pooling."""
+    if x.shape[0] == 0:
+        return torch.empty((0, w["wc"].shape[0]), dtype=torch.float32, device=x.device)
     _, _, p = trunk_scores(w, x, drop_p, seed)
     _, _, sa, sb = drop_seeds(seed)
     a_raw, _, _ = ops.gated_pool_fwd(p, w["wa"].shape[0], None, w["wc"], w["bc"], drop_p, sa, sb)
@@ -98,6 +109,14 @@ def mil_backward(w: Dict[str, torch.Tensor], s: Saved, dlogits: torch.Tensor, ds
     hg = None if grads is None else (grads["wcls"], grads["bcls"], grads["wsite"], grads["bsite"])
     g["wcls"], g["bcls"], g["wsite"], g["bsite"], dm = ops.heads_bwd(
         s.mcat, dlogits, dsite, w["wcls"], w["wsite"], dmcat_ext, hg, beta)
+    if s.x.shape[0] == 0:
+        # empty bag: nothing upstream of the pooled features received data, so those gradients are exactly zero
+        for k in ("w1", "b1", "w2", "b2", "wa", "ba", "wb", "bb", "wc", "bc"):
+            if grads is None:
+                g[k] = torch.zeros_like(w[k])
+            else:
+                g[k] = grads[k].mul_(beta)
+        return g, (torch.empty_like(s.x) if need_dx else None)
     _, _, sa, sb = drop_seeds(s.seed)
     mscale = 1.0 / (1.0 - s.drop_p) if s.drop_p > 0 else 1.0      # ReLU+Dropout outputs: zeros already carry the mask
     dp, dh, g["wc"], g["bc"] = ops.gated_pool_bwd(
