@@ -142,6 +142,32 @@ def test_full_size_properties_100k(cuda):
     assert (a.sum(1) - 1).abs().max().item() < 1e-9
 
 
+def test_million_patch_bag_duplication_property(cuda):
+    """Maximum size: a 1.1 M-patch bag (4.5 GB, M*K*4 >= 2^32: beyond the 32-bit-offset fast path of the persistent GEMMs, so the
+    64-bit generic kernels serve it). Property: repeating every row r times leaves the softmax-pooled features, the logits
+    and - because each copy carries 1/r of the attention - all gradients unchanged."""
+    from toad_amd import TOAD_fc_mtl_concat
+    params = orc.xavier_params(18, seed=2)
+    m = TOAD_fc_mtl_concat(n_classes=18); m.load_state_dict(params); m.relocate(); m.train()
+    small = torch.randn(1100, 1024, generator=torch.Generator().manual_seed(3)).to(cuda)
+    sex, label, site = torch.ones(1, device=cuda), torch.tensor([3], device=cuda), torch.tensor([1], device=cuda)
+    ce = torch.nn.CrossEntropyLoss()
+
+    def run(bag):
+        m.zero_grad()
+        out = m(bag, sex)
+        (ce(out["logits"], label) * 0.75 + ce(out["site_logits"], site) * 0.25).backward()
+        return out, {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    out_s, g_s = run(small)
+    out_b, g_b = run(small.repeat(1000, 1))
+    assert out_b["A"].shape == (2, 1_100_000)
+    assert (out_b["logits"] - out_s["logits"]).abs().max().item() <= 1e-5
+    assert (out_b["A"][:, :1100] - out_s["A"]).abs().max().item() <= 1e-4
+    for k in g_s:       # 1e-4 absolute: the two sizes run on different kernels, so ReLU-boundary flips differ (DESIGN 2)
+        assert (g_b[k] - g_s[k]).abs().max().item() <= 1e-4, k
+
+
 def test_attn_net_gated_standalone(cuda):
     """Attn_Net_Gated with its constructor defaults (L=1024, D=256, n_tasks=1; model_toad.py:19)."""
     from toad_amd import Attn_Net_Gated
