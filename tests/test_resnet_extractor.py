@@ -211,6 +211,21 @@ def test_extractor_matches_reference_features(cuda, rg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,h,w", [(1, 1, 1), (2, 7, 9), (1, 2, 31), (3, 17, 5), (1, 40, 300)])
+def test_degenerate_tile_shapes_vs_oracle(cuda, b, h, w):
+    """Tiles down to a single pixel, thin strips, non-multiples of the strides: every stage output can shrink to 1x1."""
+    from toad_amd.resnet_custom import resnet50_baseline
+    sd = ro.make_params(41)
+    model = resnet50_baseline(); model.load_state_dict(sd); model.relocate(); model.eval()
+    x = ro.make_tiles(b, h, w, 1000 + h * w)
+    with torch.no_grad():
+        f = model(x.to(cuda)).cpu()
+    ref = ro.forward(sd, x)
+    assert f.shape == ref.shape == (b, 1024)
+    assert (f - ref).abs().max().item() <= 1e-4
+
+
+@pytest.mark.gpu
 def test_full_size_properties(cuda):
     """BASELINE config 5 sizes (256x256 tiles, 160 per call - enough tiles to switch the 256-channel 3x3 to the implicit path
     for part of the chunks): size-independent properties instead of an oracle run.
