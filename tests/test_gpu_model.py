@@ -168,6 +168,38 @@ def test_million_patch_bag_duplication_property(cuda):
         assert (g_b[k] - g_s[k]).abs().max().item() <= 1e-4, k
 
 
+def test_non_default_stream_and_autograd_thread(cuda):
+    """The C ABI takes the stream explicitly: the whole path on a side stream (forward on the caller's thread, backward on
+    PyTorch's autograd worker thread) gives bitwise the results of the default stream, and two models on two streams do not
+    disturb each other (no hidden global state in the library)."""
+    from toad_amd import TOAD_fc_mtl_concat
+    params = orc.xavier_params(18, seed=4)
+    x = torch.randn(3000, 1024, generator=torch.Generator().manual_seed(9)).to(cuda)
+    sex, label, site = torch.zeros(1, device=cuda), torch.tensor([7], device=cuda), torch.tensor([0], device=cuda)
+    ce = torch.nn.CrossEntropyLoss()
+
+    def run(model):
+        model.zero_grad()
+        out = model(x, sex)
+        (ce(out["logits"], label) * 0.75 + ce(out["site_logits"], site) * 0.25).backward()
+        return out["logits"].detach().clone(), [p.grad.clone() for p in model.parameters()]
+
+    m1 = TOAD_fc_mtl_concat(n_classes=18); m1.load_state_dict(params); m1.relocate(); m1.train()
+    m2 = TOAD_fc_mtl_concat(n_classes=18); m2.load_state_dict(params); m2.relocate(); m2.train()
+    ref_logits, ref_grads = run(m1)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):                                  # interleave the two streams
+        with torch.cuda.stream(s1):
+            l1, g1 = run(m1)
+        with torch.cuda.stream(s2):
+            l2, g2 = run(m2)
+    torch.cuda.synchronize()
+    for lg, gs in ((l1, g1), (l2, g2)):
+        assert torch.equal(lg, ref_logits)
+        assert all(torch.equal(a, b) for a, b in zip(gs, ref_grads))
+
+
 def test_attn_net_gated_standalone(cuda):
     """Attn_Net_Gated with its constructor defaults (L=1024, D=256, n_tasks=1; model_toad.py:19)."""
     from toad_amd import Attn_Net_Gated
