@@ -101,4 +101,6 @@ def test_copies_overlap_with_compute(cuda):
         dp.step([(dev, sx, lab, sit)], 1)
     torch.cuda.synchronize(); t_compute = time.perf_counter() - t0
     print(f"copy {t_copy*1e3:.1f} ms  compute {t_compute*1e3:.1f} ms  pipelined {t_overlap*1e3:.1f} ms")
-    assert t_overlap < 0.8 * (t_copy + t_compute), (t_copy, t_compute, t_overlap)
+    # at least 30 % of the shorter phase must hide behind the longer one (measured: 32.8 ms against 29.0 + 17.2; the bound
+    # is 41 ms, loose enough for a noisy box, and a serialised pipeline at 46 ms still fails it)
+    assert t_overlap < t_copy + t_compute - 0.3 * min(t_copy, t_compute), (t_copy, t_compute, t_overlap)
