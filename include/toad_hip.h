@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOAD_ABI_VERSION 6
+#define TOAD_ABI_VERSION 7
 
 enum { TOAD_OK = 0, TOAD_EINVAL = -1, TOAD_ESHAPE = -2, TOAD_EWORKSPACE = -3, TOAD_EALIGN = -4 };
 enum { TOAD_ACT_NONE = 0, TOAD_ACT_RELU = 1 };
@@ -36,7 +36,21 @@ enum { TOAD_ACT_NONE = 0, TOAD_ACT_RELU = 1 };
 int toad_abi_version(void);
 const char *toad_last_error(void);
 
-/* ---- Linear layers (exact-fp32 MFMA GEMMs) ------------------------------------------ */
+/* ---- Linear layers (fp32-accurate MFMA GEMMs) ---------------------------------------- */
+
+/* Arithmetic. Products run on the fp16 matrix pipe with every fp32 operand element carried as TWO fp16 pieces,
+ * x*s = h + m (s a power of two), and three MFMA terms per product (h.h + h.m + m.h, fp32 accumulation): results are
+ * as close to the exact value as an fp32 fma chain (csrc/gemm_h2.inc, tools/split_emulation.py). The power-of-two
+ * scales come from ABS-MAX ARRAYS: amax[b] = max |X[r,:]| over rows r of the b-th block of 256 rows,
+ * toad_amax_floats(rows) floats per tensor. Every GEMM entry point
+ *   - accepts the array of its activation operand(s) (`*_amax` inputs; NULL = measured inside the call, one extra pass), and
+ *   - can emit the array of its output (`y_amax` / `dx_amax` outputs; NULL = not wanted) from its epilogue, so a chain of
+ *     layers never re-reads a tensor just to measure it. toad_absmax_rows256_f32 measures a tensor that comes from outside. */
+size_t toad_amax_floats(int64_t rows);
+int toad_absmax_rows256_f32(const float *X, int64_t M, int64_t K, float *amax, void *stream);
+/* 1 when the persistent fp16 two-piece kernel serves an [M,K] x [N,K]^T product (K % 32 == 0, N % 4 == 0, M*K*4 < 2^32);
+ * other shapes run on the older exact-fp32 kernels (same results to fp32 round-off). */
+int toad_linear_h2_ok(int64_t M, int64_t N, int64_t K);
 
 /* Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]).   bias may be NULL.
  * Replaces nn.Linear(+nn.ReLU): models/model_toad.py:59 and :62 (trunk, act=RELU) and the
@@ -44,35 +58,45 @@ const char *toad_last_error(void);
  * drop_p > 0 applies train-mode nn.Dropout(drop_p) after the activation (models/model_toad.py:61,64):
  * element (row, col) is kept iff hash(drop_seed, row*N+col) >= drop_p*2^32 and then scaled by
  * 1/(1-drop_p); the mask is never stored (toad_dropout_mask_f32 reproduces it).
- * Requires K % 4 == 0. `ws` (toad_linear_ws_bytes, also used by toad_linear_dgrad_f32) holds the
- * fp32 slabs of K-split remainder tiles of the persistent 256x256 kernel; with ws == NULL, or
- * K % 32 != 0, the generic 128x128 kernel runs instead. */
+ * Requires K % 4 == 0. `ws` (toad_linear_ws_bytes, also used by toad_linear_dgrad_f32) holds the fp32 slabs of
+ * K-split remainder tiles of the persistent 256x256 kernel, the split weight planes and, when x_amax == NULL, the
+ * measured abs-max array; with ws == NULL, or K % 32 != 0, the generic 128x128 kernel runs instead.
+ * x_amax: abs-max array of X or NULL.  y_amax: receives the abs-max array of Y, or NULL. */
 size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K);
 int toad_linear_act_fwd_f32(const float *X, const float *W, const float *bias, float *Y,
                             int64_t M, int64_t K, int64_t N, int act,
                             float drop_p, uint64_t drop_seed,
+                            const float *x_amax, float *y_amax,
                             void *ws, size_t ws_bytes, void *stream);
 
-/* dX[M,K] = (dY[M,N] W[N,K] + addend[M,K]) * (relu_src[M,K] > 0) * mask_scale
+/* dX[M,K] = (dY[M,N] W[N,K] + addend[M,K] + pool[M,K]) * (relu_src[M,K] > 0) * mask_scale
  * mask_scale = 1, or 1/(1-p) when relu_src is a ReLU+Dropout(p) output (its zeros already encode the
  * dropout mask).  `WT` is W transposed, [K,N] row-major (see toad_transpose_f32).  addend and relu_src may be
  * NULL (no add / no mask); dX may alias addend.
+ * pool (pool_T in {1,2}; 0 = none): the gradient of the attention pooling w.r.t. its input rows,
+ *   pool[r,c] = sum_t softmax_r(A_raw[:,t])[r] * dM[t,c]   (models/model_toad.py:97-98 backward),
+ * recomputed in the epilogue from pool_a_raw [M,pool_T], pool_stats [pool_T,2] (max, sum; toad_gated_pool_fwd_f32) and
+ * pool_dM [pool_T,K] instead of being read from an [M,K] buffer (toad_gated_pool_bwd_f32 then runs with dH == NULL).
+ * Needs toad_linear_h2_ok(M, K, N) and a workspace.
  * Replaces autograd's mm backward + threshold_backward behind loss.backward()
  * (utils/core_utils_mtl_concat.py:231) for models/model_toad.py:62 and :21,:25.
- * Requires N % 4 == 0. */
+ * Requires N % 4 == 0.  dy_amax: abs-max array of dY or NULL.  dx_amax: receives the abs-max array of dX, or NULL. */
 int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend,
                           const float *relu_src, float mask_scale, float *dX,
                           int64_t M, int64_t N, int64_t K,
+                          const float *pool_a_raw, const float *pool_stats, const float *pool_dM, int pool_T,
+                          const float *dy_amax, float *dx_amax,
                           void *ws, size_t ws_bytes, void *stream);
 
 /* dW[N,K] = beta*dW + dY[M,N]^T X[M,K];  db[N] = beta*db + column sums of dY (db may be NULL).
  * Split over M with a deterministic two-stage reduction through `ws`.
  * Replaces autograd's weight/bias gradient for every nn.Linear on the path
  * (models/model_toad.py:59,62,21,25 via utils/core_utils_mtl_concat.py:231).
- * Requires N % 4 == 0 and K % 4 == 0. */
+ * Requires N % 4 == 0 and K % 4 == 0.  dy_amax / x_amax: abs-max arrays of the operands or NULL. */
 size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K);
 int toad_linear_wgrad_f32(const float *dY, const float *X, float *dW, float *db,
                           int64_t M, int64_t N, int64_t K, float beta,
+                          const float *dy_amax, const float *x_amax,
                           void *ws, size_t ws_bytes, void *stream);
 
 /* out[e] = the dropout multiplier (0 or 1/(1-p)) the kernels apply to flat element e under `drop_seed`
@@ -107,16 +131,16 @@ int toad_gated_pool_fwd_f32(const float *Pa, const float *Pb, int64_t ldp, const
 /* Backward of the above (autograd mirror, utils/core_utils_mtl_concat.py:231):
  *   p[i,t]  = exp(A_raw[i,t]-max_t)/sum_t
  *   dS[i,t] = p[i,t]*(dM[t,:].H[i,:] - dM[t,:].M[t,:]) + dA_ext[i,t]   (dA_ext may be NULL)
- *   dH[i,:] = sum_t p[i,t]*dM[t,:]
+ *   dH[i,:] = sum_t p[i,t]*dM[t,:]      (dH == NULL: not written - toad_linear_dgrad_f32 recomputes it in its epilogue)
  *   dPa = (dS Wc) * b*(1-a^2),  dPb = (dS Wc) * a*b*(1-b)   with a=tanh(Pa), b=sigmoid(Pb)
  *   dWc = beta*dWc + dS^T g,  dbc = beta*dbc + column sums of dS
- * dPa/dPb have row stride ldd floats. */
+ * dPa/dPb have row stride ldd floats. dp_amax (or NULL): receives the abs-max array of the [N, ldd] dP rows. */
 size_t toad_gated_pool_bwd_ws_bytes(int64_t N, int L, int D, int T);
 int toad_gated_pool_bwd_f32(const float *Pa, const float *Pb, int64_t ldp, const float *H,
                             const float *Wc, const float *A_raw, const float *stats,
                             const float *M, const float *dM, const float *dA_ext,
                             float *dPa, float *dPb, int64_t ldd, float *dH,
-                            float *dWc, float *dbc, float beta,
+                            float *dWc, float *dbc, float beta, float *dp_amax,
                             void *ws, size_t ws_bytes,
                             int64_t N, int L, int D, int T,
                             float drop_p, uint64_t seed_a, uint64_t seed_b, void *stream);
@@ -134,15 +158,30 @@ int toad_heads_fwd_f32(const float *M, const float *sex,
                        int L, int C, void *stream);
 
 /* Backward of the heads: dWcls = beta*dWcls + dlogits^T Mcat[0], dbcls, dWsite, dbsite likewise;
- * dM[t,:] = (d{logits,site}[.] W{cls,site})[:L] + dMcat_ext[t,:L]  (dMcat_ext [2,L+1] may be NULL). */
+ * dM[t,:] = (d{logits,site}[.] W{cls,site})[:L] + dMcat_ext[t,:L]  (dMcat_ext [2,L+1] may be NULL);
+ * dsex (one float, or NULL) = gradient of the `sex` scalar that models/model_toad.py:99 appends to BOTH pooled rows:
+ *   sum_c dlogits[c] Wcls[c,L] + sum_c dsite[c] Wsite[c,L] + dMcat_ext[0,L] + dMcat_ext[1,L]. */
 int toad_heads_bwd_f32(const float *Mcat, const float *dlogits, const float *dsite,
                        const float *Wcls, const float *Wsite, const float *dMcat_ext,
-                       float *dWcls, float *dbcls, float *dWsite, float *dbsite, float *dM,
+                       float *dWcls, float *dbcls, float *dWsite, float *dbsite, float *dM, float *dsex,
                        float beta, int L, int C, void *stream);
+
+/* toad_heads_fwd_f32 + toad_mtl_ce_fwd_bwd_f32 + toad_heads_bwd_f32 in ONE single-workgroup launch (bitwise the results of
+ * the three calls): the tail of a training step (models/model_toad.py:99-107 + utils/core_utils_mtl_concat.py:213-215,231).
+ * dlogits / dsite may be NULL (not exported). */
+int toad_heads_ce_fused_f32(const float *M, const float *sex,
+                            const float *Wcls, const float *bcls, const float *Wsite, const float *bsite,
+                            const int64_t *label, const int64_t *site, float w_cls, float w_site,
+                            float *Mcat, float *logits, float *Y_prob, int64_t *Y_hat,
+                            float *site_logits, float *site_prob, int64_t *site_hat,
+                            float *loss_out, float *dlogits, float *dsite,
+                            float *dWcls, float *dbcls, float *dWsite, float *dbsite, float *dM,
+                            float beta, int L, int C, void *stream);
 
 /* Fused caller-side loss (utils/core_utils_mtl_concat.py:213-215) and its gradient:
  *   loss = w_cls*CE(logits,label) + w_site*CE(site_logits,site);  dlogits, dsite = d loss/d logits.
- * label/site point at ONE device int64 each. loss_out[3] = (loss, cls_loss, site_loss). */
+ * label/site point at ONE device int64 each. loss_out[3] = (loss, cls_loss, site_loss).
+ * A label outside [0, C) (torch's CrossEntropyLoss raises) poisons loss and gradient with NaN instead of reading out of bounds. */
 int toad_mtl_ce_fwd_bwd_f32(const float *logits, const float *site_logits,
                             const int64_t *label, const int64_t *site,
                             float w_cls, float w_site,
@@ -154,6 +193,12 @@ int toad_mtl_ce_fwd_bwd_f32(const float *logits, const float *site_logits,
 int toad_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay,
                        int64_t step, void *stream);
+
+/* SGD over a flat fp32 buffer (n % 4 == 0), identical update to torch.optim.SGD(lr, momentum, weight_decay) as built by
+ * get_optim's SGD branch (utils/utils.py:66-67: momentum 0.9): g' = g + wd*p; buf = momentum*buf + g' (buf = g' at step 1);
+ * p -= lr*buf. momentum_buf may be NULL when momentum == 0. `step` counts from 1. One launch. */
+int toad_sgd_step_f32(float *p, const float *g, float *momentum_buf, int64_t n,
+                      float lr, float momentum, float weight_decay, int64_t step, void *stream);
 
 /* ---- Feature extractor: truncated ResNet-50 (models/resnet_custom.py) -------------------- */
 /* Inference form of the reference's `resnet50_baseline` (models/resnet_custom.py:111-119): the producer of the
@@ -209,24 +254,60 @@ size_t toad_resnet50_trunc_ws_bytes(int B, int H, int W);
 int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float *const *weights, const float *const *biases,
                                 float *feat, int B, int H, int W, void *ws, size_t ws_bytes, void *stream);
 
-/* ---- Whole per-slide training step ------------------------------------------------------ */
+/* ---- Whole-slide calls: forward, backward, training step -------------------------------- */
 
-/* One call = model(data, sex) + weighted CE + loss.backward() of the reference train loop
- * (utils/core_utils_mtl_concat.py:206,213-215,231) for TOAD_fc_mtl_concat(size_arg="big"), sequenced in
- * C++ over a caller-owned arena (toad_mil_step_ws_bytes) with the kernels above, in the same order as the
- * per-op path: no host round trips or allocations between launches.
+/* The reference drives this path through three Python statements,
+ *     results = model(data, sex)      utils/core_utils_mtl_concat.py:206  (also :284,:393, eval_utils_mtl_concat.py:91)
+ *     loss.backward()                 :231
+ * and the model's forward is models/model_toad.py:90-116. The three entry points below run those statements for
+ * TOAD_fc_mtl_concat(size_arg="big" | "small") as ONE library call each, sequencing the kernels above in C++ (no host
+ * round trips, no allocations, every weight operand split by one launch, abs-max arrays handed from producer to consumer).
+ *
  *   params / grads : 12 device pointers each, slots w1 b1 w2 b2 wab bab wc bc wcls bcls wsite bsite
  *                    (wab = [Wa;Wb] stacked [2D,512], bab = [ba;bb]); grads = beta*grads + d loss/d param.
+ *   D in {256, 384}; X [N,1024] fp32, N >= 1 (an empty bag has no kernels to run: handle it in the host).
+ *   drop_p, seed   : train-mode Dropout(drop_p) masks (0 = off), four streams derived from `seed`.
+ *   x_amax         : abs-max array of X (toad_absmax_rows256_f32) or NULL = measured inside the call.
+ *
+ * Memory. `arena` (toad_mil_arena_bytes) receives everything the backward needs and everything the caller reads:
+ * toad_mil_arena_layout() returns the byte offset of each tensor in it, in this order (MIL_ARENA_SLOTS = 16 entries):
+ *   0 H1 [N,512]  1 H [N,512]  2 P [N,2D]  3 A_raw [N,2]  4 stats [2,2]  5 M [2,512]  6 Mcat [2,513]
+ *   7 logits [C]  8 Y_prob [C]  9 Y_hat (int64)  10 site_logits [2]  11 site_prob [2]  12 site_hat (int64)
+ *   13 x_amax  14 h1_amax  15 h_amax   (abs-max arrays, toad_amax_floats(N) floats each)
+ * `scratch` (toad_mil_scratch_bytes) is temporary (GEMM slabs, weight planes, gradients of activations): it can be one
+ * buffer reused by every call on a stream. */
+#define TOAD_MIL_ARENA_SLOTS 16
+size_t toad_mil_buffer_align(int64_t N);   /* offsets are relative to `arena` rounded up to this power of two (the byte counts include the slack) */
+size_t toad_mil_arena_bytes(int64_t N, int C, int D);
+int toad_mil_arena_layout(int64_t N, int C, int D, int64_t *offsets /* [TOAD_MIL_ARENA_SLOTS] */);
+size_t toad_mil_scratch_bytes(int64_t N, int C, int D);
+
+/* Forward: models/model_toad.py:90-116. attention_only != 0 stops after A_raw (:93-94; M, heads not computed). */
+int toad_mil_fwd_f32(const float *const *params, const float *X, const float *sex, int64_t N, int C, int D,
+                     float drop_p, uint64_t seed, const float *x_amax, int attention_only,
+                     void *arena, size_t arena_bytes, void *scratch, size_t scratch_bytes, void *stream);
+
+/* Backward of toad_mil_fwd_f32 for the same (params, X, arena, drop_p, seed): given dlogits [C] and dsite [2]
+ * (d loss / d logits, from the caller's loss) and optionally dA_ext [N,2] (gradient arriving through results['A']) and
+ * dMcat_ext [2,513] (through results['features']), accumulates all parameter gradients; dX [N,1024] and dsex [1] are
+ * written when non-NULL. */
+int toad_mil_bwd_f32(const float *const *params, float *const *grads, float beta, const float *X, int64_t N, int C, int D,
+                     float drop_p, uint64_t seed, const void *arena, size_t arena_bytes,
+                     const float *dlogits, const float *dsite, const float *dA_ext, const float *dMcat_ext,
+                     float *dX, float *dsex, void *scratch, size_t scratch_bytes, void *stream);
+
+/* One call = model(data, sex) + weighted CE + loss.backward() of the reference train loop
+ * (utils/core_utils_mtl_concat.py:206,213-215,231): toad_mil_fwd_f32, the fused heads/CE tail and toad_mil_bwd_f32 over one
+ * workspace (toad_mil_step_ws_bytes = arena + scratch).
  *   sex / label / site : one device float / int64 / int64.  loss_out[3] = (loss, cls CE, site CE).
  *   logits_out [C], site_logits_out [2] : optional copies of the logits.
- *   drop_p, seed : train-mode Dropout(drop_p) masks (0 = off), four streams derived from `seed`.
  *   events : NULL, or 18 hipEvent_t recorded around the fused pool forward ([0],[1]) and the eight GEMM
  *            calls ([2+2i],[3+2i]) - used by bench.py for its roofline figures. */
 size_t toad_mil_step_ws_bytes(int64_t N, int C, int D);
 int toad_mil_step_f32(const float *const *params, float *const *grads, float beta, const float *X,
                       const float *sex, const int64_t *label, const int64_t *site,
                       float w_cls, float w_site, int64_t N, int C, int D,
-                      float drop_p, uint64_t seed,
+                      float drop_p, uint64_t seed, const float *x_amax,
                       float *loss_out, float *logits_out, float *site_logits_out,
                       void *ws, size_t ws_bytes, void **events, void *stream);
 

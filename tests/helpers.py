@@ -37,6 +37,24 @@ def assert_close(a, b, atol, rtol=0.0, what=""):
     assert not bad.any(), f"{what}: max err {err.max():.3e} (tol {tol.flat[err.argmax()]:.3e}) at {np.argwhere(bad)[:3].tolist()}"
 
 
+_ORACLE_DEV = {}
+
+
+def oracle_fp32_noise(golden, name):
+    """{key: max |oracle gradient in fp32 - oracle gradient in fp64|} for a golden case (cached).
+    Several gradients on this path are sums that cancel almost completely (column sums of dS are zero by the softmax's shift
+    invariance, so d attention biases / d attention_c.bias are round-off of terms ~1e4 x larger than the result; with all rows
+    equal every attention gradient is exactly zero). For those the honest yardstick is the fp32 round-off of the computation
+    itself, measured here on the CPU restatement, not the size of the (vanishing) result."""
+    if name not in _ORACLE_DEV:
+        ci = case_inputs(golden, name)
+        _, _, g32 = orc.fwd_bwd(ci["params"], ci["x"], ci["sex"], ci["label"], ci["site"])
+        p64 = {k: v.double() for k, v in ci["params"].items()}
+        _, _, g64 = orc.fwd_bwd(p64, ci["x"].double(), ci["sex"].double(), ci["label"], ci["site"])
+        _ORACLE_DEV[name] = {k: float((g32[k].double() - g64[k]).abs().max()) for k in orc.PARAM_KEYS}
+    return _ORACLE_DEV[name]
+
+
 def check_outputs_vs_golden(golden, name, out, loss, grads, atol=1e-4):
     """out: dict of CPU tensors (reference keys + 'features'); grads: {state-dict key: tensor}."""
     pre = name + "/"
@@ -54,16 +72,42 @@ def check_outputs_vs_golden(golden, name, out, loss, grads, atol=1e-4):
     if loss is not None:
         assert abs(float(loss) - float(golden[pre + "loss"])) <= atol, name
     if grads is not None:
-        # Gradients are pinned to the REFERENCE run in fp64 (grad_sample64) with the reference's own
-        # fp32-vs-fp64 deviation (grad_dev64, full-tensor max) as the yardstick: ReLU masks flip when a
-        # pre-activation lies within fp32 roundoff of zero, so two correct fp32 implementations differ
-        # by whole dZ rows (DESIGN.md "Parity").  Bound: the north star's 1e-4 absolute, or 4x the
-        # reference's own fp32 noise where that is larger (only the x30-scaled adversarial bag).
+        # Gradients are pinned to the REFERENCE run in fp64 (grad_sample64). Tolerance is RELATIVE to each gradient's own
+        # scale (golden grad_absmax): 2e-5 of it, or 10x the fp32 noise of this very computation where that is larger - the
+        # reference's own fp32-vs-fp64 deviation (grad_dev64, full-tensor max; ReLU masks flip when a pre-activation lies within
+        # fp32 roundoff of zero, so two correct fp32 implementations differ by whole dZ rows, DESIGN.md "Parity") or the CPU
+        # restatement's (oracle_fp32_noise: the cancellation-dominated gradients). Nothing here is an absolute 1e-4 any more:
+        # |grad|max is 5e-6 for Wa/Wb, so an absolute bound would be vacuous. The flip-free test in test_gpu_model.py holds
+        # every gradient to 2e-5 of its scale without any noise allowance (also at N = 100,000).
+        gmax_all = max(float(golden[pre + "grad_absmax/" + k]) for k in orc.PARAM_KEYS)
+        onoise = oracle_fp32_noise(golden, name)
         for k in orc.PARAM_KEYS:
             g = grads[k].detach().cpu()
-            dev = float(golden[pre + "grad_dev64/" + k])
-            tol = max(atol, 4.0 * dev)
+            dev = max(float(golden[pre + "grad_dev64/" + k]), onoise[k])
+            scale = float(golden[pre + "grad_absmax/" + k])
+            tol = max(2e-5 * scale, 10.0 * dev)     # other fp32 implementations (other summation orders) differ by small multiples of the noise
+            if scale == 0.0:        # exactly zero in the reference (one-patch bag: softmax of a single score has no gradient):
+                tol = 1e-6 * gmax_all       # what an implementation returns is round-off of the cancelling terms
             assert_close(strided_sample(g), golden[pre + "grad_sample64/" + k], tol, what=f"{name}:grad64:{k}")
             assert_close(strided_sample(g), golden[pre + "grad_sample/" + k], tol + dev, what=f"{name}:grad32:{k}")
             l2 = float(golden[pre + "grad_l2_64/" + k])
-            assert abs(float(g.double().norm()) - l2) <= 5e-3 * l2 + 1e-6, (name, k, float(g.double().norm()), l2)
+            assert abs(float(g.double().norm()) - l2) <= 1e-3 * l2 + tol * g.numel() ** 0.5 + 1e-30, (name, k, float(g.double().norm()), l2)
+
+
+# gradients whose exact value is zero by symmetry: the softmax is shift invariant, so d loss / d attention_c.bias == 0 and
+# what any fp32 implementation returns is round-off of a sum whose terms have the scale of d attention_c.weight
+_SCALE_PARTNER = {"attention_net.4.attention_c.bias": "attention_net.4.attention_c.weight", "bc": "wc"}
+
+
+def grad_scale(ref: dict, key: str) -> float:
+    """|gradient|max of `key` in the reference dict `ref` (its own scale), never an absolute floor."""
+    s = float(ref[key].abs().max())
+    if key in _SCALE_PARTNER and _SCALE_PARTNER[key] in ref:
+        s = max(s, float(ref[_SCALE_PARTNER[key]].abs().max()))
+    return s
+
+
+def assert_grad_close(got, ref, rel, scale, what="", floor=0.0):
+    err = float((got.detach().cpu().double() - ref.detach().cpu().double()).abs().max())
+    tol = rel * scale + floor
+    assert err <= tol, f"{what}: max err {err:.3e} > {tol:.3e} (scale {scale:.3e}, rel {err / max(scale, 1e-300):.2e})"

@@ -30,8 +30,32 @@ def test_library_exports_every_header_symbol():
 def test_argument_errors_are_reported_without_a_gpu():
     from toad_amd import _lib
     lib = _lib.load()
-    rc = lib.toad_linear_act_fwd_f32(None, None, None, None, 4, 4, 4, 0, 0.0, 0, None, 0, None)
+    rc = lib.toad_linear_act_fwd_f32(None, None, None, None, 4, 4, 4, 0, 0.0, 0, None, None, None, 0, None)
     assert rc == -1 and b"null pointer" in lib.toad_last_error()
+    # ABI v7: whole-slide entry points and the abs-max plumbing validate before touching the device
+    import ctypes
+    one = ctypes.c_void_p(1 << 21)
+    err = lambda: lib.toad_last_error().decode()
+    assert lib.toad_amax_floats(1) == 1 and lib.toad_amax_floats(256) == 1 and lib.toad_amax_floats(257) == 2 and lib.toad_amax_floats(100000) == 391
+    assert lib.toad_absmax_rows256_f32(one, 10, 6, one, None) == -1 and "bad argument" in err()
+    assert lib.toad_linear_h2_ok(100000, 512, 1024) in (0, 1)          # (env knob TOAD_GEMM_H2 may switch the path off)
+    assert lib.toad_linear_h2_ok(100000, 512, 1000) == 0 and lib.toad_linear_h2_ok(2_000_000, 512, 1024) == 0
+    assert lib.toad_mil_arena_bytes(1000, 18, 384) > 1000 * (512 + 512 + 768 + 2) * 4
+    assert lib.toad_mil_arena_bytes(1000, 18, 100) == 0 and lib.toad_mil_scratch_bytes(0, 18, 384) == 0
+    offs = (ctypes.c_int64 * 16)()
+    assert lib.toad_mil_arena_layout(100000, 18, 384, offs) == 0
+    o = list(offs)
+    assert o[0] == 0 and all(b > a for a, b in zip(o, o[1:])) and all(x % (1 << 21) == 0 for x in o[:4]) and o[15] - o[14] == 391 * 4
+    assert lib.toad_mil_step_ws_bytes(100000, 18, 384) >= lib.toad_mil_arena_bytes(100000, 18, 384) + lib.toad_mil_scratch_bytes(100000, 18, 384)
+    p12 = (ctypes.c_void_p * 12)(*([1 << 21] * 12))
+    assert lib.toad_mil_fwd_f32(p12, one, one, 1000, 18, 100, 0.0, 0, None, 0, one, 1 << 40, one, 1 << 40, None) == -2 and "unsupported shape" in err()
+    assert lib.toad_mil_fwd_f32(p12, one, one, 1000, 18, 384, 0.0, 0, None, 0, one, 16, one, 1 << 40, None) == -3 and "arena too small" in err()
+    assert lib.toad_mil_fwd_f32(p12, one, one, 1000, 18, 384, 0.0, 0, None, 0, one, 1 << 40, one, 16, None) == -3 and "scratch too small" in err()
+    p12[3] = None
+    assert lib.toad_mil_fwd_f32(p12, one, one, 1000, 18, 384, 0.0, 0, None, 0, one, 1 << 40, one, 1 << 40, None) == -1 and "slot 3" in err()
+    assert lib.toad_mil_bwd_f32(p12, p12, 0.0, one, 1000, 18, 384, 0.0, 0, one, 1 << 40, None, one, None, None, None, None, one, 1 << 40, None) == -1
+    assert lib.toad_sgd_step_f32(one, one, None, 1024, 0.1, 0.9, 0.0, 1, None) == -1       # momentum without a buffer
+    assert lib.toad_heads_ce_fused_f32(*([None] * 8), 0.75, 0.25, *([None] * 15), 0.0, 512, 18, None) == -1
     assert lib.toad_gated_pool_ws_bytes(1000, 512, 384, 2) > 0
     assert lib.toad_gated_pool_ws_bytes(1000, 500, 384, 2) == 0      # unsupported shape
     assert lib.toad_linear_wgrad_ws_bytes(100000, 512, 1024) >= 512 * 1024 * 4

@@ -1,0 +1,252 @@
+"""GPU: the fp16 two-piece GEMM path (csrc/gemm_h2.inc) - abs-max plumbing, power-of-two scales, the recomputed pooling addend -
+and the whole-slide entry points (toad_mil_fwd_f32 / toad_mil_bwd_f32) against the per-op path and the oracle."""
+import pytest
+import torch
+
+from oracle import toad_oracle as orc
+from tests.helpers import assert_grad_close, grad_scale
+
+pytestmark = pytest.mark.gpu
+
+
+def _blockmax(t, rows=256):
+    t = t.abs()
+    return torch.stack([t[i:i + rows].max() for i in range(0, t.shape[0], rows)])
+
+
+def _rel(a, b):
+    return (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), 1e-300)
+
+
+@pytest.mark.parametrize("m,k", [(1, 512), (255, 1024), (256, 512), (257, 768), (5000, 1024), (70001, 512)])
+def test_absmax_rows256_is_exact(cuda, m, k):
+    from toad_amd import ops
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(m + k)) * 3.0
+    x[m // 2, k // 3] = -77.5                                    # a negative extreme: |.| must be taken
+    got = ops.absmax_rows256(x.to(cuda)).cpu()
+    assert got.shape == (ops.amax_floats(m),) and torch.equal(got, _blockmax(x))
+
+
+@pytest.mark.parametrize("m", [1, 300, 777, 4096, 70000])
+def test_epilogue_amax_equals_the_output_maximum(cuda, m):
+    """y_amax written by the GEMM epilogue (whole tiles) and by the fix-up kernel (K-split remainder tiles) is EXACTLY the
+    per-256-row abs-max of the stored output, with bias / ReLU / mask applied, and feeding it to the next GEMM gives bitwise
+    the result of letting that GEMM measure its operand itself."""
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(m)
+    x = torch.randn(m, 1024, generator=g); w = torch.randn(512, 1024, generator=g) * 0.05; b = torch.randn(512, generator=g)
+    y, ya = ops.linear_act_fwd(x.to(cuda), w.to(cuda), b.to(cuda), 1, want_amax=True)
+    assert torch.equal(ya.cpu(), _blockmax(y.cpu()))
+    w2 = (torch.randn(768, 512, generator=g) * 0.05).to(cuda)
+    p1 = ops.linear_act_fwd(y, w2, None, 0, x_amax=ya)
+    p2 = ops.linear_act_fwd(y, w2, None, 0)
+    assert torch.equal(p1, p2)
+    dy = torch.randn(m, 768, generator=g).to(cuda)
+    dx, da = ops.linear_dgrad(dy, ops.transpose(w2), relu_src=y, want_amax=True)
+    assert torch.equal(da.cpu(), _blockmax(dx.cpu()))
+    dw1, db1 = ops.linear_wgrad(dx, x.to(cuda), dy_amax=da, x_amax=ops.absmax_rows256(x.to(cuda)))
+    dw2, db2 = ops.linear_wgrad(dx, x.to(cuda))
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1e-12, 1.0, 1e12, 1e30])
+def test_scales_cover_the_fp32_range(cuda, scale):
+    """fp16 has 5 exponent bits: the power-of-two operand scales must bring any fp32 magnitude into range (and back)."""
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(600, 512, generator=g) * scale
+    w = torch.randn(512, 512, generator=g) * 0.05
+    y = ops.linear_act_fwd(x.to(cuda), w.to(cuda), None, 0).cpu()
+    ref = (x.double() @ w.double().t()).float()
+    assert torch.isfinite(y).all() and _rel(y, ref) <= 1e-5
+    dy = torch.randn(600, 512, generator=g) * scale
+    dw, db = ops.linear_wgrad(dy.to(cuda), x.to(cuda) / scale)
+    assert _rel(dw.cpu(), (dy.double().t() @ (x.double() / scale)).float()) <= 2e-5
+
+
+def test_row_blocks_with_very_different_magnitudes(cuda):
+    """NT products scale every 256-row tile by its own abs-max: a block of tiny rows next to a block of huge rows keeps
+    fp32-level RELATIVE accuracy in both (a single tensor-wide scale would flush the tiny block)."""
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1024, 512, generator=g)
+    x[:256] *= 1e-9; x[256:512] *= 1e7; x[768:] *= 1e-3
+    w = torch.randn(768, 512, generator=g) * 0.05
+    y = ops.linear_act_fwd(x.to(cuda), w.to(cuda), None, 0).cpu()
+    ref = (x.double() @ w.double().t()).float()
+    for i in range(0, 1024, 256):
+        assert _rel(y[i:i + 256], ref[i:i + 256]) <= 1e-5, i
+    # weights: every output column (row of W) has its own scale as well
+    w2 = w.clone(); w2[::3] *= 1e-8; w2[1::3] *= 1e6
+    y2 = ops.linear_act_fwd(x[512:768].to(cuda), w2.to(cuda), None, 0).cpu()
+    ref2 = (x[512:768].double() @ w2.double().t()).float()
+    for j in range(3):
+        assert _rel(y2[:, j::3], ref2[:, j::3]) <= 1e-5, j
+
+
+def test_zero_and_constant_operands(cuda):
+    from toad_amd import ops
+    x = torch.zeros(300, 512, device=cuda); w = torch.randn(512, 512, device=cuda)
+    b = torch.randn(512, device=cuda)
+    y, ya = ops.linear_act_fwd(x, w, b, 0, want_amax=True)
+    assert torch.equal(y, b.expand(300, 512)) and torch.equal(ya.cpu(), _blockmax(y.cpu()))
+    y0 = ops.linear_act_fwd(x, torch.zeros_like(w), None, 1)
+    assert y0.abs().max().item() == 0.0
+    ones = torch.ones(513, 512, device=cuda)
+    assert torch.equal(ops.linear_act_fwd(ones, torch.ones(512, 512, device=cuda), None, 0), torch.full((513, 512), 512.0, device=cuda))
+
+
+@pytest.mark.parametrize("n,t", [(1, 2), (300, 2), (777, 1), (5000, 2), (70000, 2)])
+def test_dgrad_with_recomputed_pool_addend(cuda, n, t):
+    """dX = (dY W + softmax(A_raw) dM) * (H > 0): the pooling gradient recomputed in the epilogue (and in the fix-up kernel)
+    equals the one the pooling backward materialises, to fp32 round-off."""
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(n + t)
+    l, d2 = 512, 768
+    dy = torch.randn(n, d2, generator=g) * 1e-3; w = torch.randn(d2, l, generator=g) * 0.05
+    h = torch.randn(n, l, generator=g).relu()
+    a_raw = torch.randn(n, t, generator=g) * 2.0; dm = torch.randn(t, l, generator=g) * 0.01
+    mx = a_raw.max(0).values; ex = (a_raw - mx).exp(); ssum = ex.sum(0)
+    stats = torch.stack([mx, ssum], 1).contiguous()
+    p = (a_raw.double() - mx.double()).exp() / ssum.double()
+    ref = ((dy.double() @ w.double() + p @ dm.double()) * (h > 0)).float()
+    dx, da = ops.linear_dgrad(dy.to(cuda), ops.transpose(w.to(cuda)), relu_src=h.to(cuda),
+                              pool=(a_raw.to(cuda), stats.to(cuda), dm.to(cuda)), want_amax=True)
+    assert _rel(dx.cpu(), ref) <= 1e-5
+    assert torch.equal(da.cpu(), _blockmax(dx.cpu()))
+    # against the materialised form through the same kernel
+    dh = (p @ dm.double()).float()
+    dx2 = ops.linear_dgrad(dy.to(cuda), ops.transpose(w.to(cuda)), addend=dh.to(cuda), relu_src=h.to(cuda))
+    assert _rel(dx, dx2) <= 2e-6
+
+
+def _model_and_bag(cuda, n, c=18, seed=0, dropout=False):
+    from toad_amd import TOAD_fc_mtl_concat
+    torch.manual_seed(seed)
+    model = TOAD_fc_mtl_concat(dropout=dropout, n_classes=c)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.05)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.relocate()
+    x = torch.randn(n, 1024, generator=torch.Generator().manual_seed(seed + 1))
+    return model, params, x
+
+
+@pytest.mark.parametrize("n,drop", [(1, 0.0), (300, 0.0), (777, 0.25), (9000, 0.0)])
+def test_whole_slide_calls_are_bitwise_the_per_op_path(cuda, n, drop):
+    """toad_mil_fwd_f32 / toad_mil_bwd_f32 (one C call each, what model(data, sex) / loss.backward() run) == the per-op
+    sequence of functional.mil_forward / mil_backward: same kernels, same order -> bitwise-equal outputs and gradients."""
+    from toad_amd import functional as F_, ops
+    model, _, x = _model_and_bag(cuda, n, seed=n)
+    w = {k: v.detach() for k, v in model._weights().items()}
+    xg = x.to(cuda); sex = torch.ones(1, device=cuda)
+    seed = 4242
+    outs, sv = F_.mil_forward(w, xg, sex, drop, seed)
+    arena = ops.mil_fwd(w, xg, sex, drop, seed)
+    c = 18
+    assert torch.equal(arena.view("logits", (1, c)), outs["logits"]) and torch.equal(arena.view("site_logits", (1, 2)), outs["site_logits"])
+    assert torch.equal(arena.view("a_raw", (n, 2)), outs["A_nt"]) and torch.equal(arena.view("mcat", (2, 513)), outs["features"])
+    assert torch.equal(arena.view("y_prob", (1, c)), outs["Y_prob"]) and torch.equal(arena.view("y_hat", (1, 1), torch.int64), outs["Y_hat"])
+    assert torch.equal(arena.view("h", (n, 512)), sv.h) and torch.equal(arena.view("p", (n, 768)), sv.p)
+    assert torch.equal(arena.view("h_amax", (ops.amax_floats(n),)), sv.h_amax)
+    g0 = torch.Generator(device=cuda).manual_seed(5)
+    dl = torch.randn(1, c, device=cuda, generator=g0); dsite = torch.randn(1, 2, device=cuda, generator=g0)
+    da = torch.randn(n, 2, device=cuda, generator=g0) * 0.01; dfe = torch.randn(2, 513, device=cuda, generator=g0) * 0.01
+    g_ref, dx_ref, dsex_ref = F_.mil_backward(w, sv, dl, dsite, da, dfe, need_dx=True, need_dsex=True)
+    grads = {k: torch.full_like(w[k], 3.0) for k in ops.STEP_SLOTS}
+    dx, dsex = ops.mil_bwd(w, grads, 0.0, xg, arena, dl, dsite, da, dfe, drop, seed, need_dx=True, need_dsex=True)
+    d = w["wa"].shape[0]
+    ref = dict(g_ref); ref["wab"] = torch.cat([g_ref["wa"], g_ref["wb"]], 0); ref["bab"] = torch.cat([g_ref["ba"], g_ref["bb"]], 0)
+    for k in ops.STEP_SLOTS:
+        assert torch.equal(grads[k], ref[k]), k
+    assert torch.equal(dx, dx_ref) and torch.equal(dsex, dsex_ref)
+    # attention_only stops after the scores
+    a_only = ops.mil_fwd(w, xg, None, drop, seed, attention_only=True).view("a_raw", (n, 2))
+    assert torch.equal(a_only, outs["A_nt"])
+
+
+def test_sex_and_bag_gradients_match_autograd_on_the_oracle(cuda):
+    """d loss / d sex flows through BOTH heads (models/model_toad.py:99 appends sex to both pooled rows) and through
+    results['features']; d loss / d data through the whole trunk. Reference: torch autograd over the oracle in fp64."""
+    model, params, x = _model_and_bag(cuda, 1500, seed=7)
+    sex = torch.tensor([1.0]); label = torch.tensor([4]); site = torch.tensor([1])
+    xg = x.to(cuda).requires_grad_(True); sg = sex.to(cuda).requires_grad_(True)
+    res = model(xg, sg, return_features=True)
+    ce = torch.nn.CrossEntropyLoss()
+    loss = ce(res["logits"], label.to(cuda)) * 0.75 + ce(res["site_logits"], site.to(cuda)) * 0.25 + 0.1 * res["features"].sum() \
+        + 0.01 * res["A"].pow(2).sum()
+    loss.backward()
+    p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    x64 = x.double().requires_grad_(True); s64 = sex.double().requires_grad_(True)
+    o, _ = orc.forward(p64, x64, s64, return_features=True)
+    l64 = ce(o["logits"], label) * 0.75 + ce(o["site_logits"], site) * 0.25 + 0.1 * o["features"].sum() + 0.01 * o["A"].pow(2).sum()
+    l64.backward()
+    assert abs(loss.item() - l64.item()) <= 1e-4 * max(abs(l64.item()), 1.0)
+    assert_grad_close(sg.grad, s64.grad, 2e-5, float(s64.grad.abs().max()))
+    assert_grad_close(xg.grad, x64.grad, 1e-4, float(x64.grad.abs().max()))     # ReLU flips allowed for: fp32 forward vs fp64
+    g64 = {k: v.grad for k, v in p64.items()}
+    for k, p in model.named_parameters():
+        assert_grad_close(p.grad, g64[k], 2e-4, grad_scale(g64, k), what=k)
+
+
+def test_backward_twice_with_retain_graph(cuda):
+    model, _, x = _model_and_bag(cuda, 400, seed=3)
+    res = model(x.to(cuda), torch.zeros(1, device=cuda))
+    loss = res["logits"].sum() + res["site_logits"].sum()
+    loss.backward(retain_graph=True)
+    g1 = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    for a, p in zip(g1, model.parameters()):
+        assert torch.equal(a, p.grad)
+
+
+def test_out_of_range_label_poisons_the_loss(cuda):
+    """torch's CrossEntropyLoss raises for a label outside [0, C); a kernel cannot - it must not read out of bounds and must
+    make the error impossible to miss: NaN loss and NaN gradients."""
+    from toad_amd import ops
+    lg = torch.randn(1, 18, device=cuda); sl = torch.randn(1, 2, device=cuda)
+    for lab, st in ((18, 0), (-1, 1), (3, 2)):
+        loss, dl, ds = ops.mtl_ce_fwd_bwd(lg, sl, torch.tensor([lab], device=cuda), torch.tensor([st], device=cuda))
+        assert torch.isnan(loss[0]).item()
+        assert torch.isnan(dl).all().item() if not 0 <= lab < 18 else torch.isnan(ds).all().item()
+    loss, dl, ds = ops.mtl_ce_fwd_bwd(lg, sl, torch.tensor([17], device=cuda), torch.tensor([1], device=cuda))
+    assert torch.isfinite(loss).all() and torch.isfinite(dl).all() and torch.isfinite(ds).all()
+
+
+def test_flat_sgd_matches_torch_sgd(cuda):
+    """toad_sgd_step_f32 == torch.optim.SGD(lr, momentum=0.9, weight_decay) (get_optim's SGD branch, utils/utils.py:66-67)."""
+    from toad_amd.optim import FlatSGD
+    torch.manual_seed(8)
+    n = 1192768
+    p0 = torch.randn(n); grads = [torch.randn(n) * 0.01 for _ in range(4)]
+    ref_p = torch.nn.Parameter(p0.clone())
+    ref = torch.optim.SGD([ref_p], lr=0.05, momentum=0.9, weight_decay=1e-5)
+    mine_p = p0.clone().to(cuda)
+    mine = FlatSGD(mine_p, lr=0.05, momentum=0.9, weight_decay=1e-5)
+    for g in grads:
+        ref_p.grad = g.clone(); ref.step()
+        mine.step(g.to(cuda))
+    assert (mine_p.cpu() - ref_p.detach()).abs().max().item() <= 2e-6
+    plain = FlatSGD(p0.clone().to(cuda), lr=0.1, momentum=0.0, weight_decay=0.0)
+    plain.step(grads[0].to(cuda))
+    assert (plain.p.cpu() - (p0 - 0.1 * grads[0])).abs().max().item() <= 1e-6
+
+
+def test_flat_adam_state_round_trip_and_stale_buffer_guard(cuda):
+    from toad_amd import TOAD_fc_mtl_concat
+    from toad_amd.dp import SlideShardedDP
+    from toad_amd.optim import FlatAdam
+    torch.manual_seed(1)
+    p = torch.randn(4096, device=cuda); g = torch.randn(4096, device=cuda)
+    a = FlatAdam(p.clone()); a.step(g); a.step(g)
+    b = FlatAdam(a.p.clone()); b.load_state_dict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.state_dict().items()})
+    a.step(g); b.step(g)
+    assert torch.equal(a.p, b.p) and b.t == 3
+    model = TOAD_fc_mtl_concat(n_classes=4); model.relocate()
+    dp = SlideShardedDP(model, "adam")
+    model.flatten_parameters()                                  # re-homes every parameter in a NEW flat buffer
+    with pytest.raises(RuntimeError, match="flat parameter buffer was replaced"):
+        dp.accumulate([], 1)

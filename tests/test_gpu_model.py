@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import toad_oracle as orc
-from tests.helpers import SLOT2KEY, case_inputs, check_outputs_vs_golden
+from tests.helpers import SLOT2KEY, assert_grad_close, case_inputs, check_outputs_vs_golden, grad_scale
 
 pytestmark = pytest.mark.gpu
 
@@ -40,11 +40,12 @@ def test_module_matches_reference_golden(cuda, golden, name):
     assert torch.equal(a_only, res["A"][0].detach())
 
 
-@pytest.mark.parametrize("name", ["n777", "n1024_sat", "n10000"])
+@pytest.mark.parametrize("name", ["n777", "n1024_sat", "n10000", "n100000"])
 def test_backward_chain_tight_with_identical_relu_masks(cuda, golden, name):
     """Flip-free check of the whole backward chain: the oracle's hand-written backward is run on
     the activations the GPU forward saved (so ReLU masks are identical on both sides); what is left
-    is rounding only, so the bound is 2e-5 of each gradient's own scale."""
+    is rounding only, so the bound is 2e-5 of each gradient's OWN scale (|grad|max of the fp64 result; no absolute
+    floor - |dWa|max is 5e-6) for all 14 gradients, including the headline size N = 100,000."""
     from toad_amd import functional as F_
     ci = case_inputs(golden, name)
     w = {s: ci["params"][k].to(cuda) for s, k in SLOT2KEY.items()}
@@ -53,13 +54,17 @@ def test_backward_chain_tight_with_identical_relu_masks(cuda, golden, name):
     g, _ = F_.mil_backward(w, sv, dl.to(cuda), ds.to(cuda))
     saved_cpu = orc.Saved(x=ci["x"], h1=sv.h1.cpu(), h=sv.h.cpu(), p=sv.p.cpu(), a_raw=sv.a_raw.cpu(),
                           m=sv.m.cpu(), mcat=sv.mcat.cpu(), sex=ci["sex"])
-    og = orc.backward({k: v.double() for k, v in ci["params"].items()},
-                      orc.Saved(**{k: (v.double() if (v is not None and v.is_floating_point()) else v) for k, v in saved_cpu.__dict__.items()}),
-                      dl.double(), ds.double())
+    s64 = orc.Saved(**{k: (v.double() if (v is not None and v.is_floating_point()) else v) for k, v in saved_cpu.__dict__.items()})
+    og = orc.backward({k: v.double() for k, v in ci["params"].items()}, s64, dl.double(), ds.double())
+    # Three of the 14 gradients are sums that cancel almost completely (d attention_a/b biases = column sums of dP, d attention_c
+    # bias = column sums of dS = 0 by the softmax's shift invariance): their fp32 round-off is set by the size of the cancelling
+    # terms, not of the result. The allowance for that is measured, not assumed: 10 x the deviation of the SAME backward evaluated
+    # in plain fp32 on the CPU from its fp64 value. For the well-conditioned gradients that deviation is ~1e-6 of the scale and the
+    # 2e-5 bound is the one that binds.
+    o32 = orc.backward(ci["params"], saved_cpu, dl, ds)
     for sl, k in SLOT2KEY.items():
-        ref = og[k]
-        err = (g[sl].cpu().double() - ref).abs().max().item()
-        assert err <= 2e-5 * max(ref.abs().max().item(), 1e-4) + 1e-9, (name, sl, err, ref.abs().max().item())
+        noise = (o32[k].double() - og[k]).abs().max().item()
+        assert_grad_close(g[sl], og[k], 2e-5, grad_scale(og, k), what=f"{name}:{sl}", floor=10.0 * noise)
 
 
 def test_module_random_bag_vs_oracle(cuda):
@@ -80,9 +85,12 @@ def test_module_random_bag_vs_oracle(cuda):
     for k in ("logits", "Y_prob", "site_logits", "site_prob", "A"):
         assert (res[k].detach().cpu() - o_out[k]).abs().max().item() <= 1e-4, k
     assert abs(loss.item() - o_loss.item()) <= 1e-4
+    # yardstick for ReLU-boundary flips: the oracle's own fp32-vs-fp64 deviation on this bag (as in the goldens)
+    p64 = {k: v.double() for k, v in params.items()}
+    _, _, g64 = orc.fwd_bwd(p64, x.double(), sex.double(), label, site)
     for k, p in model.named_parameters():
-        ref = o_grads[k]
-        assert (p.grad.cpu() - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-2), k
+        dev = (o_grads[k].double() - g64[k]).abs().max().item()
+        assert_grad_close(p.grad, g64[k], 2e-5, grad_scale(g64, k), what=k, floor=4.0 * dev)
 
 
 def test_fused_loss_path_equals_autograd_path(cuda):
@@ -101,8 +109,9 @@ def test_fused_loss_path_equals_autograd_path(cuda):
     lossv, dl, ds = ops.mtl_ce_fwd_bwd(outs["logits"], outs["site_logits"], label, site)
     g, _ = F_.mil_backward(w, saved, dl, ds)
     sp = model._slot_params()
+    ref = {k: sp[k].grad for k in F_.SLOTS}
     for k in F_.SLOTS:      # same kernels; only d(loss)/d(logits) comes from a different CE implementation
-        assert (g[k] - sp[k].grad).abs().max().item() <= 1e-5 * max(sp[k].grad.abs().max().item(), 1e-2), k
+        assert_grad_close(g[k], ref[k], 1e-5, grad_scale(ref, k), what=k)
     dest = {k: torch.ones_like(sp[k]) for k in F_.SLOTS}
     g2, _ = F_.mil_backward(w, saved, dl, ds, grads=dest, beta=1.0)
     for k in F_.SLOTS:
@@ -135,7 +144,14 @@ def test_full_size_properties_100k(cuda):
     r3, g3 = run(x[perm].contiguous())
     assert (r3["logits"] - r1["logits"]).abs().max().item() <= 1e-4
     assert (r3["A"][:, torch.argsort(perm)] - r1["A"]).abs().max().item() <= 1e-5
-    assert (g3 - g1).abs().max().item() <= 1e-4 * max(g1.abs().max().item(), 1e-2)
+    off = 0
+    names = [k for k, _ in model.named_parameters()]
+    gd1, gd3 = {}, {}
+    for k, p in model.named_parameters():
+        gd1[k], gd3[k] = g1[off:off + p.numel()], g3[off:off + p.numel()]
+        off += p.numel()
+    for k in names:         # summation order over 100,000 rows changes: 5e-4 of each gradient's own scale
+        assert_grad_close(gd3[k], gd1[k], 5e-4, grad_scale(gd1, k), what=f"perm:{k}")
     feats = r1["features"][:, :512]
     assert feats.min().item() >= 0.0                                 # H = relu(...) >= 0, weights >= 0
     a = torch.softmax(r1["A"].double(), dim=1)
@@ -219,9 +235,9 @@ def test_attn_net_gated_standalone(cuda):
     a.sin().sum().backward(); ref.sin().sum().backward()
     mine = [net.attention_a[0].weight, net.attention_a[0].bias, net.attention_b[0].weight, net.attention_b[0].bias,
             net.attention_c.weight, net.attention_c.bias]
-    for p, r in zip(mine, prm):
-        assert (p.grad.cpu() - r.grad).abs().max().item() <= 1e-4 * max(r.grad.abs().max().item(), 1e-2)
-    assert (xg.grad.cpu() - xr.grad).abs().max().item() <= 1e-4 * max(xr.grad.abs().max().item(), 1e-2)
+    for p, r in zip(mine, prm):        # smooth (no ReLU): rounding only, 1e-4 of each gradient's own scale
+        assert_grad_close(p.grad, r.grad, 1e-4, float(r.grad.abs().max()))
+    assert_grad_close(xg.grad, xr.grad, 1e-4, float(xr.grad.abs().max()))
 
 
 def test_dp_step_single_gpu_matches_mean_of_oracle_gradients(cuda):
@@ -248,16 +264,21 @@ def test_dp_step_single_gpu_matches_mean_of_oracle_gradients(cuda):
     dp.flat_grad.fill_(123.0)                       # stale contents must be overwritten, not accumulated
     losses = dp.step(slides, global_slides=3)
     mean = {k: torch.zeros_like(v) for k, v in params.items()}
+    mean64 = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in params.items()}
+    p64 = {k: v.double() for k, v in params.items()}
     for s in slides_cpu:
         _, _, g = orc.fwd_bwd(params, *s)
+        _, _, g64 = orc.fwd_bwd(p64, s[0].double(), s[1].double(), s[2], s[3])
         for k in mean:
             mean[k] += g[k] / 3
+            mean64[k] += g64[k] / 3
     new = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     for k, p in model.named_parameters():
-        ref = mean[k]
-        # 1e-4 absolute (north star): a ReLU-boundary flip moves a whole dW row by ~1e-5 here
-        assert (p.grad.cpu() - ref).abs().max().item() <= 1e-4, k
-        assert (new[k] - (params[k] - 0.5 * ref)).abs().max().item() <= 1e-4, k
+        ref = mean64[k]
+        # relative to each gradient's own scale; the allowance for ReLU-boundary flips is 4x the oracle's own fp32-vs-fp64 deviation
+        dev = (mean[k].double() - ref).abs().max().item()
+        assert_grad_close(p.grad, ref, 2e-5, grad_scale(mean64, k), what=k, floor=4.0 * dev)
+        assert (new[k].double() - (params[k].double() - 0.5 * p.grad.cpu().double())).abs().max().item() <= 1e-6, k   # SGD moved by -lr * bucket
     assert len(losses) == 3 and losses[0].shape == (3,)
 
 
@@ -327,7 +348,7 @@ def test_train_mode_dropout_matches_oracle_with_the_same_masks(cuda, n):
     for k in orc.PARAM_KEYS:
         ref = og[k]
         got = grads[inv[k]].grad.cpu()
-        assert (got - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-3), k
+        assert_grad_close(got, ref, 1e-4, grad_scale(og, k), what=k)     # fp32 oracle backward on identical masks: rounding only
     # a second forward draws a new seed -> different masks; eval() -> deterministic, equals the no-dropout oracle
     res2 = model(x.to(cuda), sex.to(cuda))
     assert not torch.equal(res2["logits"], res["logits"])
@@ -400,5 +421,8 @@ def test_size_arg_small_end_to_end(cuda):
     o_out, o_loss, o_grads = orc.fwd_bwd(params, x, sex, label, site)
     for k in ("logits", "site_logits", "A"):
         assert (res[k].detach().cpu() - o_out[k]).abs().max().item() <= 1e-4, k
+    p64 = {k: v.double() for k, v in params.items()}
+    _, _, g64 = orc.fwd_bwd(p64, x.double(), sex.double(), label, site)
     for k, p in model.named_parameters():
-        assert (p.grad.cpu() - o_grads[k]).abs().max().item() <= 1e-4, k
+        dev = (o_grads[k].double() - g64[k]).abs().max().item()
+        assert_grad_close(p.grad, g64[k], 2e-5, grad_scale(g64, k), what=k, floor=4.0 * dev)

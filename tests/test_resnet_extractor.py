@@ -198,13 +198,21 @@ def test_extractor_matches_reference_features(cuda, rg):
         one = model(x[3:4])
     assert (full[3:4] - one).abs().max().item() <= 1e-5
     import toad_amd.resnet_custom as rc
-    old = rc.MAX_TILES_PER_CALL
+    assert rc.max_tiles_per_call(256, 256) == 512 and rc.max_tiles_per_call(512, 512) == 128 and rc.max_tiles_per_call(8, 8) == 4096
+    old = rc.max_tiles_per_call
     try:
-        rc.MAX_TILES_PER_CALL = 2
+        rc.max_tiles_per_call = lambda h, w: 2
         with torch.no_grad():
             assert (model(x) - full).abs().max().item() <= 1e-5
     finally:
-        rc.MAX_TILES_PER_CALL = old
+        rc.max_tiles_per_call = old
+    # weights loaded THROUGH A PARENT module or edited in place must drop the folded-weight cache (round-1 advice)
+    with torch.no_grad():
+        model.layer1[0].bn1.weight.mul_(1.5)
+        changed = model(x)
+        model.layer1[0].bn1.weight.div_(1.5)
+        back = model(x)
+    assert (changed - full).abs().max().item() > 1e-4 and (back - full).abs().max().item() <= 1e-5
     model.train()
     with pytest.raises(RuntimeError):
         model(x)
@@ -244,12 +252,12 @@ def test_full_size_properties(cuda):
         f = model(x)
         assert torch.equal(f, model(x))
         fp = model(x[perm])
-        old = rc.MAX_TILES_PER_CALL
+        old = rc.max_tiles_per_call
         try:
-            rc.MAX_TILES_PER_CALL = 32
+            rc.max_tiles_per_call = lambda h, w: 32
             f32 = model(x)
         finally:
-            rc.MAX_TILES_PER_CALL = old
+            rc.max_tiles_per_call = old
     scale = f.abs().max().item()
     assert torch.isfinite(f).all() and (f - f32).abs().max().item() <= 1e-5 * max(scale, 1.0)
     assert (fp - f[perm]).abs().max().item() <= 1e-5 * max(scale, 1.0)

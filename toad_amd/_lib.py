@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TOAD_HIP_LIB", os.path.join(_HERE, "libtoad_hip.so"))   # override: kernel A/B builds only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 P, I64, I, F, SZ, U64 = c_void_p, c_int64, c_int, c_float, c_size_t, c_uint64
 
@@ -19,19 +19,24 @@ P, I64, I, F, SZ, U64 = c_void_p, c_int64, c_int, c_float, c_size_t, c_uint64
 SIGNATURES = {
     "toad_abi_version": (I, []),
     "toad_last_error": (c_char_p, []),
+    "toad_amax_floats": (SZ, [I64]),
+    "toad_absmax_rows256_f32": (I, [P, I64, I64, P, P]),
+    "toad_linear_h2_ok": (I, [I64, I64, I64]),
     "toad_linear_ws_bytes": (SZ, [I64, I64, I64]),
-    "toad_linear_act_fwd_f32": (I, [P, P, P, P, I64, I64, I64, I, F, U64, P, SZ, P]),
-    "toad_linear_dgrad_f32": (I, [P, P, P, P, F, P, I64, I64, I64, P, SZ, P]),
+    "toad_linear_act_fwd_f32": (I, [P, P, P, P, I64, I64, I64, I, F, U64, P, P, P, SZ, P]),
+    "toad_linear_dgrad_f32": (I, [P, P, P, P, F, P, I64, I64, I64, P, P, P, I, P, P, P, SZ, P]),
     "toad_dropout_mask_f32": (I, [P, I64, F, U64, P]),
     "toad_linear_wgrad_ws_bytes": (SZ, [I64, I64, I64]),
-    "toad_linear_wgrad_f32": (I, [P, P, P, P, I64, I64, I64, F, P, SZ, P]),
+    "toad_linear_wgrad_f32": (I, [P, P, P, P, I64, I64, I64, F, P, P, P, SZ, P]),
     "toad_transpose_f32": (I, [P, P, I64, I64, P]),
     "toad_gated_pool_ws_bytes": (SZ, [I64, I, I, I]),
     "toad_gated_pool_fwd_f32": (I, [P, P, I64, P, P, P, P, P, P, P, SZ, I64, I, I, I, F, U64, U64, P]),
     "toad_gated_pool_bwd_ws_bytes": (SZ, [I64, I, I, I]),
-    "toad_gated_pool_bwd_f32": (I, [P, P, I64, P, P, P, P, P, P, P, P, P, I64, P, P, P, F, P, SZ, I64, I, I, I, F, U64, U64, P]),
+    "toad_gated_pool_bwd_f32": (I, [P, P, I64, P, P, P, P, P, P, P, P, P, I64, P, P, P, F, P, P, SZ, I64, I, I, I, F, U64, U64, P]),
     "toad_heads_fwd_f32": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P]),
-    "toad_heads_bwd_f32": (I, [P, P, P, P, P, P, P, P, P, P, P, F, I, I, P]),
+    "toad_heads_bwd_f32": (I, [P, P, P, P, P, P, P, P, P, P, P, P, F, I, I, P]),
+    "toad_heads_ce_fused_f32": (I, [P, P, P, P, P, P, P, P, F, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, F, I, I, P]),
+    "toad_sgd_step_f32": (I, [P, P, P, I64, F, F, F, I64, P]),
     "toad_mtl_ce_fwd_bwd_f32": (I, [P, P, P, P, F, F, P, P, P, I, P]),
     "toad_adam_step_f32": (I, [P, P, P, P, I64, F, F, F, F, F, I64, P]),
     "toad_linear_act_res_fwd_f32": (I, [P, P, P, P, P, I64, I64, I64, I, P, SZ, P]),
@@ -44,8 +49,14 @@ SIGNATURES = {
     "toad_avgpool_nhwc_f32": (I, [P, P, I, I, I, P]),
     "toad_resnet50_trunc_ws_bytes": (SZ, [I, I, I]),
     "toad_resnet50_trunc_fwd_f32": (I, [P, P, P, P, I, I, I, P, SZ, P]),
+    "toad_mil_buffer_align": (SZ, [I64]),
+    "toad_mil_arena_bytes": (SZ, [I64, I, I]),
+    "toad_mil_arena_layout": (I, [I64, I, I, P]),
+    "toad_mil_scratch_bytes": (SZ, [I64, I, I]),
+    "toad_mil_fwd_f32": (I, [P, P, P, I64, I, I, F, U64, P, I, P, SZ, P, SZ, P]),
+    "toad_mil_bwd_f32": (I, [P, P, F, P, I64, I, I, F, U64, P, SZ, P, P, P, P, P, P, P, SZ, P]),
     "toad_mil_step_ws_bytes": (SZ, [I64, I, I]),
-    "toad_mil_step_f32": (I, [P, P, F, P, P, P, P, F, F, I64, I, I, F, U64, P, P, P, P, SZ, P, P]),
+    "toad_mil_step_f32": (I, [P, P, F, P, P, P, P, F, F, I64, I, I, F, U64, P, P, P, P, P, SZ, P, P]),
 }
 
 _lib = None

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtoad_hip.so")
 SOURCES = ["capi.hip", "gemm_f32.hip", "gated_pool.hip", "heads.hip", "step.hip", "conv.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(REPO, "include", "toad_hip.h")] + \
-    [os.path.join(CSRC, f) for f in ("gemm_nt_f32.inc", "gemm_nt_split.inc", "gemm_tn.inc", "gemm_narrow.inc")]
+    [os.path.join(CSRC, f) for f in ("gemm_nt_f32.inc", "gemm_nt_split.inc", "gemm_tn.inc", "gemm_h2.inc", "gemm_narrow.inc")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
          "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 
@@ -27,30 +27,35 @@ def _stale(obj: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "") -> str:
+    """Build libtoad_hip{tag}.so. `defines` / `tag` produce an A/B variant next to the shipped library (e.g.
+    defines=("TOAD_H2_C_SPLIT",), tag="_csplit"; select it at run time with TOAD_HIP_LIB=<path>)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    lib = LIB.replace(".so", tag + ".so")
     objs = []
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, src.replace(".hip", tag + ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or procs or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    if "--csplit" in sys.argv:          # A/B arm: plain-C operand split instead of the v_fma_mix asm block (same results)
+        print(build(force="--force" in sys.argv, defines=("TOAD_H2_C_SPLIT",), tag="_csplit"))
+    else:
+        print(build(force="--force" in sys.argv))

@@ -58,6 +58,23 @@ __device__ __forceinline__ float drop_keep(uint64_t idx, const DropArgs &d) {   
 }
 
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+// ---- abs-max arrays (csrc/gemm_h2.inc): amax[b] = max |x| over rows [256 b, 256 b + 256) of a tensor, stored as the bit
+// pattern of a non-negative float so that an unsigned atomic max orders it. Producers (GEMM epilogues, pooling backward)
+// fill it; the fp16 two-piece GEMMs derive their power-of-two operand scales from it.
+constexpr int H2_ROWBLK = 256;
+__device__ __forceinline__ float h2_wave_max(float v) {          // wave-wide max of non-negative floats
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ void h2_atomic_amax(float *slot, float v) {     // v >= 0
+    atomicMax(reinterpret_cast<unsigned *>(slot), __builtin_bit_cast(unsigned, v));
+}
+__device__ __forceinline__ float h2_absmax4(f32x4 v) {
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])),
+                           __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+}
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 // streaming store: the line is not kept dirty in L2 for the next kernel to flush (GEMM outputs are consumed by the NEXT launch)
 __device__ __forceinline__ void st4s(float *p, f32x4 v) {
@@ -67,5 +84,21 @@ __device__ __forceinline__ void st4s(float *p, f32x4 v) {
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
 #endif
 }
+
+// ---- host-side launchers of the fp16 two-piece GEMMs (defined in gemm_f32.hip next to their kernels; used by step.hip) ----
+struct H2Operand { const float *src; int64_t sn, sk; int64_t N, K; unsigned short *planes; float *binv; };   // B[n,k] = src[n*sn + k*sk]
+struct H2Pool { const float *a_raw, *stats, *dM; int T; };                                                   // recomputed pooling addend (T = 0: none)
+struct EpiScalars { int relu; float mask_scale; DropArgs drop; };                                            // epilogue scalars of every NT kernel
+bool h2_nt_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc);
+size_t h2_planes_bytes(int64_t N, int64_t K);
+size_t h2_binv_bytes(int64_t N);
+size_t h2_slab_bytes();
+int launch_split_h2(const H2Operand *ops, int n, hipStream_t st, const char *what);
+int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax, hipStream_t st, const char *what);
+int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C,
+                 int64_t ldc, int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
+                 const float *mask_src, H2Pool pool, float *slabs, float *y_amax, hipStream_t st, const char *what);
+int launch_wgrad(const float *dY, const float *dy_amax, const float *X, const float *x_amax, float *dW, float *db, int64_t M,
+                 int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what);
 
 }  // namespace toad

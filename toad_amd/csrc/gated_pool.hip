@@ -78,8 +78,9 @@ __device__ __forceinline__ float gate_g(float x, float y) {
     return (u - 1.f) * __builtin_amdgcn_rcpf((u + 1.f) * (1.f + v));
 }
 
-// Partial record written by each block: [T][L] acc then [T][2] (m,l)
-__host__ __device__ inline int64_t pool_partial_floats(int L, int T) { return (int64_t)T * L + 2 * T; }
+// Partial record written by each block: [T][L] acc then [T][2] (m,l), padded to a multiple of 4 floats so that every record
+// (and the 16-byte accesses into it) stays 16-byte aligned for any T
+__host__ __device__ inline int64_t pool_partial_floats(int L, int T) { return ((int64_t)T * L + 2 * T + 3) & ~(int64_t)3; }
 
 // ------------------------------------------------------------------------------------------
 // forward
@@ -297,8 +298,8 @@ __global__ __launch_bounds__(256) void gated_pool_combine_kernel(const float *__
 // ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
-// Per-block partial: [T][D] dWc then [T] dbc
-__host__ __device__ inline int64_t bwd_partial_floats(int D, int T) { return (int64_t)T * D + T; }
+// Per-block partial: [T][D] dWc then [T] dbc, padded to a multiple of 4 floats (16-byte aligned records)
+__host__ __device__ inline int64_t bwd_partial_floats(int D, int T) { return ((int64_t)T * D + T + 3) & ~(int64_t)3; }
 
 template <int T, int DQ, int LQ>
 __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
     const float *__restrict__ Wc, const float *__restrict__ A_raw, const float *__restrict__ stats,
     const float *__restrict__ Mp, const float *__restrict__ dM, const float *__restrict__ dA_ext,
     float *__restrict__ dPa, float *__restrict__ dPb, int64_t ldd, float *__restrict__ dH,
-    float *__restrict__ partials, int N, DropArgs drop_a, DropArgs drop_b) {
+    float *__restrict__ partials, float *__restrict__ dp_amax, int N, DropArgs drop_a, DropArgs drop_b) {
     constexpr int D = DQ * 4 * LPR, L = LQ * 4 * LPR;
     const bool dropping = drop_a.thresh != 0;
     __shared__ __attribute__((aligned(16))) float s_dm[T][L];
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
             ds[t] = (dA_ext && valid) ? dA_ext[rr * T + t] : 0.f;
         }
 
-        // --- H side: dot_t = dM[t].H[row], dH[row] = sum_t p_t dM[t]
+        // --- H side: dot_t = dM[t].H[row], dH[row] = sum_t p_t dM[t] (dH == NULL: the dgrad of the attention Linear recomputes it)
         float dot[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) dot[t] = 0.f;
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
                 for (int e = 0; e < 4; ++e) dot[t] = fmaf(d[e], hv[j][e], dot[t]);
                 o += p[t] * d;
             }
-            if (valid) st4(dhp + 4 * LPR * j, o);
+            if (valid && dH) st4(dhp + 4 * LPR * j, o);
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -398,6 +399,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
         // --- P side
         float *dpa = dPa + rr * ldd + c * 4;
         float *dpb = dPb + rr * ldd + c * 4;
+        float pmax = 0.f;                                   // abs-max of the dP values this lane stores in this step
 #pragma unroll
         for (int j = 0; j < DQ; ++j) {
             f32x4 oa, ob;
@@ -428,7 +430,12 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
             if (valid) {
                 st4(dpa + 4 * LPR * j, oa);
                 st4(dpb + 4 * LPR * j, ob);
+                pmax = __builtin_fmaxf(pmax, __builtin_fmaxf(h2_absmax4(oa), h2_absmax4(ob)));
             }
+        }
+        if (dp_amax) {                                      // a step's rows lie inside one 256-row block (256 % ROWS_PER_BLOCK_STEP == 0)
+            pmax = h2_wave_max(pmax);
+            if (lane == 0) h2_atomic_amax(dp_amax + (tile * ROWS_PER_BLOCK_STEP) / H2_ROWBLK, pmax);
         }
     }
 
@@ -527,11 +534,11 @@ static void launch_fwd(int L, int D, int T, int grid, hipStream_t st, const floa
 static void launch_bwd(int L, int D, int T, int grid, hipStream_t st, const float *Pa, const float *Pb, int64_t ldp,
                        const float *H, const float *Wc, const float *A_raw, const float *stats, const float *M,
                        const float *dM, const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH,
-                       float *partials, int N, DropArgs da, DropArgs db) {
+                       float *partials, float *dp_amax, int N, DropArgs da, DropArgs db) {
 #define TOAD_BWD_CASE(TT, DD, LL)                                                                             \
     if (T == TT && D == DD && L == LL) {                                                                      \
         hipLaunchKernelGGL((gated_pool_bwd_kernel<TT, DD / (4 * LPR), LL / (4 * LPR)>), dim3(grid), dim3(POOL_THREADS), 0, st, Pa, \
-                           Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, partials, N, da, db); \
+                           Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, partials, dp_amax, N, da, db); \
         return;                                                                                               \
     }
     TOAD_BWD_CASE(2, 384, 512)
@@ -591,21 +598,23 @@ extern "C" size_t toad_gated_pool_bwd_ws_bytes(int64_t N, int L, int D, int T) {
 extern "C" int toad_gated_pool_bwd_f32(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc,
                                         const float *A_raw, const float *stats, const float *M, const float *dM,
                                         const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH,
-                                        float *dWc, float *dbc, float beta, void *ws, size_t ws_bytes, int64_t N,
-                                        int L, int D, int T, float drop_p, uint64_t seed_a, uint64_t seed_b,
+                                        float *dWc, float *dbc, float beta, float *dp_amax, void *ws, size_t ws_bytes,
+                                        int64_t N, int L, int D, int T, float drop_p, uint64_t seed_a, uint64_t seed_b,
                                         void *stream) {
     const char *what = "toad_gated_pool_bwd_f32";
     if (!(drop_p >= 0.f && drop_p < 1.f)) { set_error("%s: drop_p must be in [0,1)", what); return TOAD_EINVAL; }
     const DropArgs da = make_drop(drop_p, seed_a), db = make_drop(drop_p, seed_b);
-    if (!Pa || !Pb || !H || !Wc || !A_raw || !stats || !M || !dM || !dPa || !dPb || !dH || !dWc || !dbc || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (!Pa || !Pb || !H || !Wc || !A_raw || !stats || !M || !dM || !dPa || !dPb || !dWc || !dbc || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (N <= 0 || N > INT32_MAX - 64) { set_error("%s: bad N", what); return TOAD_EINVAL; }
     if (!shape_ok(L, D, T)) { set_error("%s: unsupported shape L=%d D=%d T=%d", what, L, D, T); return TOAD_ESHAPE; }
     if (ldp < D || ldp % 4 != 0 || ldd < D || ldd % 4 != 0) { set_error("%s: bad row stride", what); return TOAD_ESHAPE; }
-    if (!aligned16(Pa) || !aligned16(Pb) || !aligned16(H) || !aligned16(dPa) || !aligned16(dPb) || !aligned16(dH) || !aligned16(ws)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (!aligned16(Pa) || !aligned16(Pb) || !aligned16(H) || !aligned16(dPa) || !aligned16(dPb) || (dH && !aligned16(dH)) || !aligned16(ws)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
     if (ws_bytes < toad_gated_pool_bwd_ws_bytes(N, L, D, T)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     const int grid = pool_grid(N);
-    launch_bwd(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, (float *)ws, (int)N, da, db);
+    static_assert(H2_ROWBLK % ROWS_PER_BLOCK_STEP == 0, "a block step must not straddle two abs-max blocks");
+    if (dp_amax) (void)hipMemsetAsync(dp_amax, 0, (size_t)((N + H2_ROWBLK - 1) / H2_ROWBLK) * sizeof(float), st);
+    launch_bwd(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, (float *)ws, dp_amax, (int)N, da, db);
     int rc = check_launch(what);
     if (rc) return rc;
     const int n = T * D + T;

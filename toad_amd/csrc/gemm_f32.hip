@@ -3,9 +3,11 @@
 // -fgpu-rdc), organised as:
 //   gemm_nt_f32.inc    generic 128x128 NT kernel; exact-fp32 persistent 256x256 NT kernel (v_mfma_f32_32x32x2_f32, the A/B arm);
 //                      the per-XCD tile plan, the shared epilogue, the K-split fix-up
-//   gemm_nt_split.inc  SHIPPED forward / dgrad: persistent 256x256 NT kernel on the bf16 pipe with x = h + m + l (six MFMA
+//   gemm_nt_split.inc  extractor convolutions (and the A/B arm TOAD_GEMM_H2=0): persistent 256x256 NT kernel on the bf16 pipe with x = h + m + l (six MFMA
 //                      terms = fp32-equivalent results), weight planes pre-split into the LDS image
 //   gemm_tn.inc        wgrad: generic, exact-fp32 persistent and SHIPPED split-bf16 persistent TN kernels; slab reduction; transpose
+//   gemm_h2.inc        SHIPPED MIL GEMMs (forward / dgrad / wgrad): persistent 256x256 kernels on the fp16 pipe with two-piece
+//                      operands (x*s = h + m, three MFMA terms, power-of-two scales from per-256-row abs-max arrays)
 //   gemm_narrow.inc    512x64 / 256x128 narrow-tile split-bf16 NT kernels with implicit convolution / stem gathers in the LDS-DMA
 //   this file          shared constants, launch selection, the extern "C" entry points declared in include/toad_hip.h
 //
@@ -32,8 +34,7 @@ constexpr int TN_LD = 128;
 constexpr int TN_TILE = BK * TN_LD;
 constexpr int TN_SMEM = 2 * 2 * TN_TILE * (int)sizeof(float);   // 65,536 B
 
-// epilogue scalars shared by every NT kernel (plain scalars only: pointers stay direct kernel arguments)
-struct EpiScalars { int relu; float mask_scale; DropArgs drop; };
+// EpiScalars (common.h): epilogue scalars shared by every NT kernel (plain scalars only: pointers stay direct kernel arguments)
 
 // XCD-aware block -> tile map: all column tiles of one row tile run on the same XCD (same L2),
 // back to back, so the A panel is fetched from HBM once and re-read from L2.
@@ -48,6 +49,7 @@ __device__ __forceinline__ bool map_tile(int tiles_m, int tiles_n, int &tm, int 
 #include "gemm_nt_f32.inc"
 #include "gemm_nt_split.inc"
 #include "gemm_tn.inc"
+#include "gemm_h2.inc"
 #include "gemm_narrow.inc"
 
 // ------------------------------------------------------------------------------------------
@@ -96,6 +98,111 @@ static bool narrow_ok(int64_t M, int64_t N, int64_t K, int64_t ldc, const float 
     const bool wide_ok = addend && K <= narrow_res_kmax();       // residual GEMMs with a short reduction: epilogue-bound, see DESIGN 10
     return narrow_enabled() && ws && (N <= 128 || wide_ok) && N % 4 == 0 && K % BK == 0 && ldc % 4 == 0 && M < (1ll << 31) &&
            (!bias || aligned16(bias)) && (!addend || aligned16(addend));
+}
+
+// ---- h2 (fp16 two-piece) path ---------------------------------------------------------------------------------
+static int h2_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("TOAD_GEMM_H2");             // A/B knob; default on
+        v = e ? atoi(e) : 1;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_h2_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, H2_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_h2_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, H2_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_h2_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM);
+    }
+    return v;
+}
+// shapes the persistent h2 NT kernel serves (32-bit row offsets of A, whole 32-deep stages, 16-byte output rows)
+bool h2_nt_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc) {
+    return h2_enabled() && M >= 1 && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && lda % 4 == 0 && (uint64_t)M * lda * 4 < (1ull << 32);
+}
+size_t h2_planes_bytes(int64_t N, int64_t K) { return (size_t)((N + PB - 1) / PB) * PB * (size_t)K * 4; }   // two fp16 planes
+size_t h2_slab_bytes() { return (size_t)PB_GRID * PB * PB * sizeof(float); }
+size_t h2_binv_bytes(int64_t N) { return (size_t)((N + PB - 1) / PB) * PB * sizeof(float); }
+
+// split up to 6 weight operands into planes + inverse row scales with ONE launch
+int launch_split_h2(const H2Operand *ops, int n, hipStream_t st, const char *what) {
+    H2SplitBatch b;
+    b.n = n;
+    int waves = 0;
+    for (int i = 0; i < 6; ++i) {
+        if (i < n) {
+            const int tiles_n = (int)((ops[i].N + PB - 1) / PB);
+            b.d[i] = H2SplitDesc{ops[i].src, ops[i].sn, ops[i].sk, ops[i].planes, ops[i].binv, (int)ops[i].N, (int)ops[i].K, tiles_n, waves};
+            waves += tiles_n * PB;
+        } else {
+            b.d[i] = H2SplitDesc{nullptr, 0, 0, nullptr, nullptr, 0, 0, 0, INT32_MAX};
+        }
+    }
+    b.total_waves = waves;
+    hipLaunchKernelGGL(split_planes_h2_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, b);
+    return check_launch(what);
+}
+int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax, hipStream_t st, const char *what) {
+    const int nblk = (int)h2_nblk(M);
+    (void)hipMemsetAsync(amax, 0, (size_t)nblk * sizeof(float), st);
+    hipLaunchKernelGGL(absmax_rows256_kernel, dim3(4, nblk), dim3(256), 0, st, X, ld, (int)M, (int)K, amax);
+    return check_launch(what);
+}
+// C = epi(A . B^T) with pre-split B (planes + binv) and the abs-max array of A; y_amax (zeroed by the caller) receives the abs-max of C
+int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C,
+                        int64_t ldc, int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
+                        const float *mask_src, H2Pool pool, float *slabs, float *y_amax, hipStream_t st, const char *what) {
+    const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
+    if (pool.T > 0 && addend) { set_error("%s: an addend buffer and the recomputed pooling addend are mutually exclusive", what); return TOAD_EINVAL; }
+    if (pool.T > 0)
+        hipLaunchKernelGGL(gemm_nt_h2_big_kernel<true>, dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, a_amax, planes, binv, C, ldc, (int)M,
+                           (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL(gemm_nt_h2_big_kernel<false>, dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, a_amax, planes, binv, C, ldc, (int)M,
+                           (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, tiles_m, tiles_n);
+    int rc = check_launch(what);
+    if (rc) return rc;
+    int max_rem = 0;                                   // fix-up grid: only as many tile rows as some XCD has remainder tiles
+    for (int x = 0; x < kNumXCD; ++x) { const int r = nt_plan(x, tiles_m, tiles_n, (int)(K / BK)).rem; if (r > max_rem) max_rem = r; }
+    if (max_rem > 0) {
+        hipLaunchKernelGGL(nt_fixup_h2_kernel, dim3(64, max_rem, kNumXCD), dim3(256), 0, st, (const float *)slabs, a_amax, binv, C, ldc,
+                           (int)M, (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, y_amax, tiles_m, tiles_n);
+        rc = check_launch(what);
+    }
+    return rc;
+}
+
+// Self-contained NT product for the per-op entry points: B[n,k] = Bsrc[n*bsn + k*bsk]. Uses the h2 kernel when the shape allows
+// (splitting B and, when a_amax == NULL, measuring A inside `ws`), else the older paths (launch_nt). y_amax, when requested, is
+// always produced (by the epilogue, or by a pass over C on the fallback paths).
+static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
+                     const float *mask_src, void *ws, hipStream_t st, const char *what);
+static int launch_nt_auto(const float *A, int64_t lda, const float *a_amax, const float *B, int64_t ldb, float *C, int64_t ldc,
+                          int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend, const float *mask_src,
+                          H2Pool pool, float *y_amax, void *ws, hipStream_t st, const char *what) {
+    if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (bias && !aligned16(bias)) || (addend && !aligned16(addend)) ||
+        (mask_src && !aligned16(mask_src))) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (M > INT32_MAX - BM || N > INT32_MAX - BN || K > INT32_MAX - BK) { set_error("%s: dimension too large", what); return TOAD_ESHAPE; }
+    if (y_amax) (void)hipMemsetAsync(y_amax, 0, (size_t)h2_nblk(M) * sizeof(float), st);
+    if (ws && ldb == K && h2_nt_ok(M, N, K, lda, ldc)) {
+        char *w = reinterpret_cast<char *>(ws);
+        float *slabs = reinterpret_cast<float *>(w);
+        w += (size_t)PB_GRID * PB * PB * sizeof(float);
+        unsigned short *planes = reinterpret_cast<unsigned short *>(w);
+        w += h2_planes_bytes(N, K);
+        float *binv = reinterpret_cast<float *>(w);
+        w += h2_binv_bytes(N);
+        float *amax_ws = reinterpret_cast<float *>(w);
+        if (!a_amax) {
+            if (int rc = launch_absmax(A, lda, M, K, amax_ws, st, what)) return rc;
+            a_amax = amax_ws;
+        }
+        const H2Operand op{B, ldb, 1, N, K, planes, binv};
+        if (int rc = launch_split_h2(&op, 1, st, what)) return rc;
+        return launch_nt_h2(A, lda, a_amax, planes, binv, C, ldc, M, N, K, bias, es, addend, mask_src, pool, slabs, y_amax, st, what);
+    }
+    if (pool.T > 0) { set_error("%s: the recomputed pooling addend needs the h2 kernel (K %% 32 == 0, M*K*4 < 2^32, workspace)", what); return TOAD_ESHAPE; }
+    int rc = launch_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, es, addend, mask_src, ws, st, what);
+    if (rc || !y_amax) return rc;
+    hipLaunchKernelGGL(absmax_rows256_kernel, dim3(4, (int)h2_nblk(M)), dim3(256), 0, st, C, ldc, (int)M, (int)N, y_amax);
+    return check_launch(what);
 }
 
 static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
@@ -216,7 +323,20 @@ extern "C" size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K) {
     (void)M;
     // one 256x256 fp32 slab per persistent block (64 MiB) + the three bf16 planes of the weight operand
     const size_t tiles_n = (size_t)((N + PB - 1) / PB), kpad = (size_t)((K + BK - 1) / BK * BK);
-    return (size_t)PB_GRID * PB * PB * sizeof(float) + tiles_n * PB * kpad * 6 + 256;
+    // (the h2 path needs 4 bytes per weight element + inverse scales + the abs-max array of A; the 6-byte planes of the older split cover it)
+    return (size_t)PB_GRID * PB * PB * sizeof(float) + tiles_n * PB * kpad * 6 + tiles_n * PB * sizeof(float) +
+           (size_t)(h2_nblk(M > 0 ? M : 1) + 64) * sizeof(float) + 256;
+}
+
+extern "C" int toad_linear_h2_ok(int64_t M, int64_t N, int64_t K) { return h2_nt_ok(M, N, K, K, N) ? 1 : 0; }
+extern "C" size_t toad_amax_floats(int64_t rows) { return (size_t)h2_nblk(rows > 0 ? rows : 1); }
+
+extern "C" int toad_absmax_rows256_f32(const float *X, int64_t M, int64_t K, float *amax, void *stream) {
+    const char *what = "toad_absmax_rows256_f32";
+    if (!X || !amax || M <= 0 || K <= 0 || K % 4 != 0) { set_error("%s: bad argument", what); return TOAD_EINVAL; }
+    if (M > INT32_MAX - 256) { set_error("%s: M too large", what); return TOAD_ESHAPE; }
+    if (!aligned16(X)) { set_error("%s: X must be 16-byte aligned", what); return TOAD_EALIGN; }
+    return launch_absmax(X, K, M, K, amax, (hipStream_t)stream, what);
 }
 
 static int check_ws(void *ws, size_t ws_bytes, int64_t M, int64_t N, int64_t K, const char *what) {
@@ -226,15 +346,17 @@ static int check_ws(void *ws, size_t ws_bytes, int64_t M, int64_t N, int64_t K, 
 }
 
 extern "C" int toad_linear_act_fwd_f32(const float *X, const float *W, const float *bias, float *Y, int64_t M,
-                                        int64_t K, int64_t N, int act, float drop_p, uint64_t drop_seed, void *ws,
-                                        size_t ws_bytes, void *stream) {
+                                        int64_t K, int64_t N, int act, float drop_p, uint64_t drop_seed,
+                                        const float *x_amax, float *y_amax, void *ws, size_t ws_bytes, void *stream) {
     const char *what = "toad_linear_act_fwd_f32";
     if (!X || !W || !Y) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (act != TOAD_ACT_NONE && act != TOAD_ACT_RELU) { set_error("%s: bad act %d", what, act); return TOAD_EINVAL; }
     if (!(drop_p >= 0.f && drop_p < 1.f)) { set_error("%s: drop_p must be in [0,1)", what); return TOAD_EINVAL; }
     if (int rc = check_ws(ws, ws_bytes, M, N, K, what)) return rc;
+    if (M <= 0 || N <= 0 || K <= 0) { set_error("%s: non-positive dimension", what); return TOAD_EINVAL; }
     EpiScalars es{act == TOAD_ACT_RELU, 1.f, make_drop(drop_p, drop_seed)};
-    return launch_nt(X, K, W, K, Y, N, M, N, K, bias, es, nullptr, nullptr, ws, (hipStream_t)stream, what);
+    return launch_nt_auto(X, K, x_amax, W, K, Y, N, M, N, K, bias, es, nullptr, nullptr, H2Pool{nullptr, nullptr, nullptr, 0}, y_amax, ws,
+                          (hipStream_t)stream, what);
 }
 
 extern "C" int toad_linear_act_res_fwd_f32(const float *X, const float *W, const float *bias, const float *residual, float *Y,
@@ -287,14 +409,19 @@ extern "C" int toad_stem_conv_s2d_f32(const float *Xs, const float *Wf, const fl
 }
 
 extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend, const float *relu_src,
-                                      float mask_scale, float *dX, int64_t M, int64_t N, int64_t K, void *ws,
-                                      size_t ws_bytes, void *stream) {
+                                      float mask_scale, float *dX, int64_t M, int64_t N, int64_t K,
+                                      const float *pool_a_raw, const float *pool_stats, const float *pool_dM, int pool_T,
+                                      const float *dy_amax, float *dx_amax, void *ws, size_t ws_bytes, void *stream) {
     const char *what = "toad_linear_dgrad_f32";
     if (!dY || !WT || !dX) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (M <= 0 || N <= 0 || K <= 0) { set_error("%s: non-positive dimension", what); return TOAD_EINVAL; }
+    if (pool_T < 0 || pool_T > 2 || (pool_T > 0 && (!pool_a_raw || !pool_stats || !pool_dM))) { set_error("%s: bad pooling-addend arguments", what); return TOAD_EINVAL; }
+    if (pool_T > 0 && (!aligned16(pool_dM) || (pool_T == 2 && ((uintptr_t)pool_a_raw & 7)))) { set_error("%s: pooling-addend pointers misaligned", what); return TOAD_EALIGN; }
     if (int rc = check_ws(ws, ws_bytes, M, K, N, what)) return rc;
     // dX[M,K] = dY[M,N] . WT[K,N]^T : an NT product with reduction dim N
     EpiScalars es{0, mask_scale, make_drop(0.f, 0)};
-    return launch_nt(dY, N, WT, N, dX, K, M, K, N, nullptr, es, addend, relu_src, ws, (hipStream_t)stream, what);
+    return launch_nt_auto(dY, N, dy_amax, WT, N, dX, K, M, K, N, nullptr, es, addend, relu_src, H2Pool{pool_a_raw, pool_stats, pool_dM, pool_T},
+                          dx_amax, ws, (hipStream_t)stream, what);
 }
 
 static bool tn_big_ok(int64_t M, int64_t N, int64_t K) {
@@ -313,34 +440,38 @@ extern "C" size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K) {
     const WgradPlan p = wgrad_plan(M, N, K);
     const TnPlan q = tn_plan(M, N, K);
     const int ns = p.nsplit > q.nsplit ? p.nsplit : q.nsplit;
-    return (size_t)ns * (size_t)(N * K + N) * sizeof(float);
+    // slabs (+ bias slabs), then: 2 scale floats, 2 abs-max arrays (operands measured here when the caller has none)
+    return (size_t)ns * (size_t)(N * K + N) * sizeof(float) + (size_t)(2 * h2_nblk(M) + 64) * sizeof(float);
 }
 
-extern "C" int toad_linear_wgrad_f32(const float *dY, const float *X, float *dW, float *db, int64_t M, int64_t N,
-                                      int64_t K, float beta, void *ws, size_t ws_bytes, void *stream) {
-    const char *what = "toad_linear_wgrad_f32";
-    if (!dY || !X || !dW || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
-    if (M <= 0 || N <= 0 || K <= 0) { set_error("%s: non-positive dimension", what); return TOAD_EINVAL; }
-    if (N % 4 != 0 || K % 4 != 0) { set_error("%s: N and K must be multiples of 4", what); return TOAD_ESHAPE; }
-    if (M > INT32_MAX - 4096) { set_error("%s: M too large", what); return TOAD_ESHAPE; }
-    if (!aligned16(dY) || !aligned16(X) || !aligned16(dW) || !aligned16(ws)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
-    if (ws_bytes < toad_linear_wgrad_ws_bytes(M, N, K)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
-    hipStream_t st = (hipStream_t)stream;
+// dW = beta*dW + dY^T X (+ db). dy_amax / x_amax: abs-max arrays of the operands (NULL -> measured here).
+int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, const float *x_amax, float *dW, float *db, int64_t M,
+                        int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what) {
     float *slab = (float *)ws;
     int nsplit;
     int rc;
+    bool h2 = false;
+    float *scales = nullptr;
     if (tn_big_ok(M, N, K)) {
         const TnPlan q = tn_plan(M, N, K);
         nsplit = q.nsplit;
         float *cs = db ? slab + (size_t)nsplit * N * K : nullptr;
         static int tn_split = -1;
         if (tn_split < 0) {
-            const char *e = getenv("TOAD_GEMM_SPLIT");     // A/B knob
+            const char *e = getenv("TOAD_GEMM_SPLIT");     // A/B knob (exact-fp32 arm when 0 and TOAD_GEMM_H2=0)
             tn_split = e ? atoi(e) : 1;
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_split_big_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM);
         }
-        if (tn_split)
+        if (h2_enabled()) {
+            h2 = true;
+            scales = slab + (size_t)nsplit * (size_t)(N * K + N);
+            float *amax_ws = scales + 16;
+            if (!dy_amax) { if ((rc = launch_absmax(dY, N, M, N, amax_ws, st, what))) return rc; dy_amax = amax_ws; }
+            if (!x_amax) { float *a2 = amax_ws + h2_nblk(M) + 16; if ((rc = launch_absmax(X, K, M, K, a2, st, what))) return rc; x_amax = a2; }
+            hipLaunchKernelGGL(gemm_tn_h2_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, dy_amax, X, K, x_amax, slab, cs, scales,
+                               (int)M, (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
+        } else if (tn_split)
             hipLaunchKernelGGL(gemm_tn_split_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, X, K, slab, cs, (int)M,
                                (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
         else
@@ -367,8 +498,24 @@ extern "C" int toad_linear_wgrad_f32(const float *dY, const float *X, float *dW,
     const int64_t n = N * K, n2 = db ? N : 0;
     int rgrid = (int)(((n + n2) / 4 + 255) / 256);
     if (rgrid > 4096) rgrid = 4096;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, st, slab, dW, n, cs, db, n2, nsplit, beta);
+    if (h2)
+        hipLaunchKernelGGL(slab_reduce_h2_kernel, dim3(rgrid), dim3(256), 0, st, slab, dW, n, cs, db, n2, nsplit, beta, scales);
+    else
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, st, slab, dW, n, cs, db, n2, nsplit, beta);
     return check_launch(what);
+}
+
+extern "C" int toad_linear_wgrad_f32(const float *dY, const float *X, float *dW, float *db, int64_t M, int64_t N,
+                                      int64_t K, float beta, const float *dy_amax, const float *x_amax, void *ws, size_t ws_bytes,
+                                      void *stream) {
+    const char *what = "toad_linear_wgrad_f32";
+    if (!dY || !X || !dW || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (M <= 0 || N <= 0 || K <= 0) { set_error("%s: non-positive dimension", what); return TOAD_EINVAL; }
+    if (N % 4 != 0 || K % 4 != 0) { set_error("%s: N and K must be multiples of 4", what); return TOAD_ESHAPE; }
+    if (M > INT32_MAX - 4096) { set_error("%s: M too large", what); return TOAD_ESHAPE; }
+    if (!aligned16(dY) || !aligned16(X) || !aligned16(dW) || !aligned16(ws)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (ws_bytes < toad_linear_wgrad_ws_bytes(M, N, K)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
+    return launch_wgrad(dY, dy_amax, X, x_amax, dW, db, M, N, K, beta, ws, (hipStream_t)stream, what);
 }
 
 extern "C" int toad_transpose_f32(const float *in, float *out, int64_t rows, int64_t cols, void *stream) {

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float *__restrict_
                                                          const float *__restrict__ dsite, const float *__restrict__ Wcls,
                                                          const float *__restrict__ Wsite, const float *__restrict__ dMcat_ext,
                                                          float *dWcls, float *dbcls, float *dWsite, float *dbsite,
-                                                         float *dM, float beta, int L, int C) {
+                                                         float *dM, float *dsex, float beta, int L, int C) {
     const int LP = L + 1;
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int r = blockIdx.y;
@@ -96,6 +96,13 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float *__restrict_
         const float d1 = fmaf(dsite[1], Wsite[LP + k], dsite[0] * Wsite[k]);
         dM[k] = d0 + (dMcat_ext ? dMcat_ext[k] : 0.f);
         dM[L + k] = d1 + (dMcat_ext ? dMcat_ext[LP + k] : 0.f);
+    } else if (dsex) {
+        // k == L: the `sex` column that models/model_toad.py:99 concatenates to BOTH pooled rows -> its gradient sums both heads
+        float d = 0.f;
+        for (int c = 0; c < C; ++c) d = fmaf(dlogits[c], Wcls[(int64_t)c * LP + L], d);
+        d = fmaf(dsite[1], Wsite[LP + L], fmaf(dsite[0], Wsite[L], d));
+        if (dMcat_ext) d += dMcat_ext[L] + dMcat_ext[LP + L];
+        dsex[0] = d;
     }
 }
 
@@ -107,8 +114,11 @@ __device__ float wave_ce(const float *lg, int n, int64_t y, float wgt, float *dl
     float s = 0.f;
     for (int i = lane; i < n; i += 64) s += expf(lg[i] - mx);
     s = wave_sum(s);
-    for (int i = lane; i < n; i += 64) dlg[i] = wgt * (expf(lg[i] - mx) / s - (i == (int)y ? 1.f : 0.f));
-    return (logf(s) + mx) - lg[y];
+    // a label outside [0, n) makes torch's CrossEntropyLoss raise; a kernel cannot, so it poisons the loss and the gradient
+    // (NaN propagates to every parameter gradient and is impossible to miss) instead of reading out of bounds
+    const bool bad = y < 0 || y >= n;
+    for (int i = lane; i < n; i += 64) dlg[i] = bad ? __builtin_nanf("") : wgt * (expf(lg[i] - mx) / s - (i == (int)y ? 1.f : 0.f));
+    return bad ? __builtin_nanf("") : (logf(s) + mx) - lg[y];
 }
 __global__ __launch_bounds__(64) void mtl_ce_kernel(const float *logits, const float *site_logits, const int64_t *label,
                                                      const int64_t *site, float w_cls, float w_site, float *loss_out,
@@ -120,6 +130,73 @@ __global__ __launch_bounds__(64) void mtl_ce_kernel(const float *logits, const f
         loss_out[0] = w_cls * lc + w_site * ls;
         loss_out[1] = lc;
         loss_out[2] = ls;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// heads forward + weighted CE + heads backward in ONE single-workgroup launch (the per-slide tail of the fused step:
+// three dependent launches of O(10 kFLOP) cost ~25 us of pure latency on small bags). Same arithmetic, in the same order,
+// as heads_fwd_kernel -> mtl_ce_kernel -> heads_bwd_kernel, so the results are bitwise those of the three-kernel chain.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void heads_ce_fused_kernel(
+    const float *__restrict__ M, const float *__restrict__ sex, const float *__restrict__ Wcls, const float *__restrict__ bcls,
+    const float *__restrict__ Wsite, const float *__restrict__ bsite, const int64_t *__restrict__ label,
+    const int64_t *__restrict__ site, float w_cls, float w_site, float *Mcat, float *logits, float *Y_prob, int64_t *Y_hat,
+    float *site_logits, float *site_prob, int64_t *site_hat, float *loss_out, float *dlogits, float *dsite, float *dWcls,
+    float *dbcls, float *dWsite, float *dbsite, float *dM, float beta, int L, int C) {
+    extern __shared__ float s_all[];                 // [2][L+1] Mcat | [C] logits | [2] site logits | [C] dlogits | [2] dsite
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int LP = L + 1;
+    float *s_m = s_all, *s_lg = s_all + 2 * LP, *s_sl = s_lg + C, *s_dl = s_sl + 2, *s_ds = s_dl + C;
+    const float sx = sex[0];
+    for (int e = tid; e < 2 * LP; e += 1024) {
+        const int t = e / LP, k = e % LP;
+        const float v = k < L ? M[t * L + k] : sx;
+        s_m[e] = v;
+        Mcat[e] = v;
+    }
+    __syncthreads();
+    for (int r = wave; r < C + 2; r += 16) {
+        const float *w = r < C ? Wcls + (int64_t)r * LP : Wsite + (int64_t)(r - C) * LP;
+        const float *x = r < C ? s_m : s_m + LP;
+        float p = 0.f;
+        for (int k = lane; k < LP; k += 64) p = fmaf(w[k], x[k], p);
+        p = wave_sum(p);
+        if (lane == 0) {
+            if (r < C) { const float v = p + bcls[r]; logits[r] = v; s_lg[r] = v; }
+            else { const float v = p + bsite[r - C]; site_logits[r - C] = v; s_sl[r - C] = v; }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) wave_softmax_argmax(s_lg, C, Y_prob, Y_hat, lane);
+    if (wave == 1) wave_softmax_argmax(s_sl, 2, site_prob, site_hat, lane);
+    if (wave == 2) {
+        const float lc = wave_ce(s_lg, C, label[0], w_cls, s_dl, lane);
+        const float ls = wave_ce(s_sl, 2, site[0], w_site, s_ds, lane);
+        if (lane == 0) { loss_out[0] = w_cls * lc + w_site * ls; loss_out[1] = lc; loss_out[2] = ls; }
+    }
+    __syncthreads();
+    if (dlogits) for (int i = tid; i < C; i += 1024) dlogits[i] = s_dl[i];
+    if (dsite && tid < 2) dsite[tid] = s_ds[tid];
+    // backward: (C + 2) weight rows of L+1 columns, then the two dM rows
+    const int total = (C + 3) * LP;
+    for (int e = tid; e < total; e += 1024) {
+        const int r = e / LP, k = e % LP;
+        if (r < C) {
+            const int64_t o = (int64_t)r * LP + k;
+            dWcls[o] = (beta != 0.f ? beta * dWcls[o] : 0.f) + s_dl[r] * s_m[k];
+            if (k == 0) dbcls[r] = (beta != 0.f ? beta * dbcls[r] : 0.f) + s_dl[r];
+        } else if (r < C + 2) {
+            const int c = r - C, o = c * LP + k;
+            dWsite[o] = (beta != 0.f ? beta * dWsite[o] : 0.f) + s_ds[c] * s_m[LP + k];
+            if (k == 0) dbsite[c] = (beta != 0.f ? beta * dbsite[c] : 0.f) + s_ds[c];
+        } else if (k < L) {
+            float d0 = 0.f;
+            for (int c = 0; c < C; ++c) d0 = fmaf(s_dl[c], Wcls[(int64_t)c * LP + k], d0);
+            const float d1 = fmaf(s_ds[1], Wsite[LP + k], s_ds[0] * Wsite[k]);
+            dM[k] = d0;
+            dM[L + k] = d1;
+        }
     }
 }
 
@@ -174,12 +251,12 @@ extern "C" int toad_heads_fwd_f32(const float *M, const float *sex, const float 
 
 extern "C" int toad_heads_bwd_f32(const float *Mcat, const float *dlogits, const float *dsite, const float *Wcls,
                                    const float *Wsite, const float *dMcat_ext, float *dWcls, float *dbcls, float *dWsite,
-                                   float *dbsite, float *dM, float beta, int L, int C, void *stream) {
+                                   float *dbsite, float *dM, float *dsex, float beta, int L, int C, void *stream) {
     const char *what = "toad_heads_bwd_f32";
     if (!Mcat || !dlogits || !dsite || !Wcls || !Wsite || !dWcls || !dbcls || !dWsite || !dbsite || !dM) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (L <= 0 || L > 8192 || C <= 0 || C > 1024 || C > L) { set_error("%s: unsupported L=%d C=%d", what, L, C); return TOAD_ESHAPE; }
     hipLaunchKernelGGL(heads_bwd_kernel, dim3((L + 1 + 255) / 256, C + 3), dim3(256), 0, (hipStream_t)stream, Mcat, dlogits, dsite,
-                       Wcls, Wsite, dMcat_ext, dWcls, dbcls, dWsite, dbsite, dM, beta, L, C);
+                       Wcls, Wsite, dMcat_ext, dWcls, dbcls, dWsite, dbsite, dM, dsex, beta, L, C);
     return check_launch(what);
 }
 
@@ -191,5 +268,52 @@ extern "C" int toad_mtl_ce_fwd_bwd_f32(const float *logits, const float *site_lo
     if (C <= 0 || C > 1024) { set_error("%s: unsupported C=%d", what, C); return TOAD_ESHAPE; }
     hipLaunchKernelGGL(mtl_ce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, logits, site_logits, label, site, w_cls,
                        w_site, loss_out, dlogits, dsite, C);
+    return check_launch(what);
+}
+
+extern "C" int toad_heads_ce_fused_f32(const float *M, const float *sex, const float *Wcls, const float *bcls, const float *Wsite,
+                                        const float *bsite, const int64_t *label, const int64_t *site, float w_cls, float w_site,
+                                        float *Mcat, float *logits, float *Y_prob, int64_t *Y_hat, float *site_logits,
+                                        float *site_prob, int64_t *site_hat, float *loss_out, float *dlogits, float *dsite,
+                                        float *dWcls, float *dbcls, float *dWsite, float *dbsite, float *dM, float beta, int L,
+                                        int C, void *stream) {
+    const char *what = "toad_heads_ce_fused_f32";
+    if (!M || !sex || !Wcls || !bcls || !Wsite || !bsite || !label || !site || !Mcat || !logits || !Y_prob || !Y_hat || !site_logits ||
+        !site_prob || !site_hat || !loss_out || !dWcls || !dbcls || !dWsite || !dbsite || !dM) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (L <= 0 || L > 8192 || C <= 0 || C > 1024 || C > L) { set_error("%s: unsupported L=%d C=%d", what, L, C); return TOAD_ESHAPE; }
+    const size_t smem = (size_t)(2 * (L + 1) + 2 * C + 4) * sizeof(float);
+    hipLaunchKernelGGL(heads_ce_fused_kernel, dim3(1), dim3(1024), smem, (hipStream_t)stream, M, sex, Wcls, bcls, Wsite, bsite, label,
+                       site, w_cls, w_site, Mcat, logits, Y_prob, Y_hat, site_logits, site_prob, site_hat, loss_out, dlogits, dsite,
+                       dWcls, dbcls, dWsite, dbsite, dM, beta, L, C);
+    return check_launch(what);
+}
+
+// Flat SGD (get_optim's SGD branch, utils/utils.py:66-67: optim.SGD(lr, momentum=0.9, weight_decay=reg)) over one buffer:
+//   g' = g + wd*p;  buf = momentum*buf + g' (buf = g' on the first step);  p -= lr*buf      - torch.optim.SGD's update.
+__global__ __launch_bounds__(256) void sgd_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ mom,
+                                                   int64_t n, float lr, float momentum, float wd, int first) {
+    const int64_t n4 = n >> 2;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        f32x4 pp = ld4(p + 4 * e), gg = ld4(g + 4 * e);
+        f32x4 bb = mom ? ld4(mom + 4 * e) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] + wd * pp[k];
+            bb[k] = (mom && !first) ? momentum * bb[k] + gk : gk;
+            pp[k] -= lr * bb[k];
+        }
+        st4(p + 4 * e, pp);
+        if (mom) st4(mom + 4 * e, bb);
+    }
+}
+extern "C" int toad_sgd_step_f32(float *p, const float *g, float *momentum_buf, int64_t n, float lr, float momentum,
+                                  float weight_decay, int64_t step, void *stream) {
+    const char *what = "toad_sgd_step_f32";
+    if (!p || !g || n <= 0 || step < 1 || (momentum != 0.f && !momentum_buf)) { set_error("%s: bad argument", what); return TOAD_EINVAL; }
+    if (n % 4 != 0 || !aligned16(p) || !aligned16(g) || (momentum_buf && !aligned16(momentum_buf))) { set_error("%s: n must be a multiple of 4 and pointers 16-byte aligned", what); return TOAD_EALIGN; }
+    int grid = (int)((n / 4 + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, momentum != 0.f ? momentum_buf : nullptr, n, lr,
+                       momentum, weight_decay, step == 1 ? 1 : 0);
     return check_launch(what);
 }

@@ -1,125 +1,342 @@
-// step.hip — one C-ABI call for the whole per-slide training step of TOAD's MIL path:
-// forward (trunk, stacked attention GEMM, fused pool, heads), the caller's weighted CE
-// (utils/core_utils_mtl_concat.py:213-215) and the full backward, sequenced in C++ over a
-// caller-owned arena. Same kernels, same order and same results as the per-op entry points
-// (toad_amd/functional.py); what disappears is ~30 host round trips and ~40 allocations per
-// slide, which dominate for the small bags of real cohorts (a 256-patch step is launch-bound).
+// step.hip — whole-slide entry points of TOAD's MIL path: forward, backward and the fused training step.
+//
+// The reference drives the path with `results = model(data, sex)` and `loss.backward()` (utils/core_utils_mtl_concat.py:206,231;
+// forward = models/model_toad.py:90-116). Here each of those is ONE C-ABI call that sequences the kernels of this library in C++
+// over caller-owned memory: a forward ARENA (saved activations, outputs, abs-max arrays - what the backward and the caller read)
+// and a reusable SCRATCH (GEMM slabs, split weight planes, gradients of activations). What disappears against the per-op path
+// is ~30 host round trips and ~40 allocations per slide, per-call weight re-splitting (all weight operands of a pass are split
+// by one launch; the dgrad operands are read transposed in place, no transpose launches), the [N,512] dH_pool round trip (the
+// dgrad epilogue recomputes it), and three dependent tail launches (heads + CE + heads backward are one single-workgroup kernel
+// in the fused step).
 #include "common.h"
 
 namespace toad {
 
-// Sub-buffers start on 2 MiB boundaries (like separate large device allocations do): with 256-B packing the
-// pool kernels, which stream P, H, dP and dH concurrently, ran 9-17 % slower (HBM channel aliasing between the
-// streams); measured with rocprofv3 on the same kernels, profiles/.
-static inline size_t align256(size_t x) { return (x + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1); }
+struct MilShape { int64_t N; int C, D; };
+constexpr int kL0 = 1024, kL = 512, kT = 2;          // size_arg "big"/"small": [1024, 512, D] (models/model_toad.py:56)
 
-struct Arena {
-    char *base; size_t off, cap;
-    template <typename T> T *take(size_t n) {
-        T *p = reinterpret_cast<T *>(base + off);
-        off = align256(off + n * sizeof(T));
-        return p;
-    }
+// Sub-buffers of a large bag start on 2 MiB boundaries (like separate large device allocations do): with 256-B packing the
+// pool kernels, which stream P, H and dP concurrently, ran 9-17 % slower (HBM channel aliasing between the streams; measured
+// with rocprofv3 on the same kernels, profiles/). Small bags pack at 4 KiB so that a 256-patch slide does not hold 30 MB.
+static inline size_t big_align(int64_t N) { return N >= 8192 ? ((size_t)1 << 21) : ((size_t)1 << 12); }
+static inline size_t up(size_t x, size_t a) { return (x + a - 1) & ~(a - 1); }
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes, size_t align) { off = up(off, align); const size_t o = off; off += bytes; return o; }
 };
 
-struct StepDims { int L0, L, D, T; };
-static const StepDims kDims = {1024, 512, 384, 2};     // size_arg = "big" (models/model_toad.py:56)
+// ---- forward arena -------------------------------------------------------------------------------------------------
+enum { A_H1 = 0, A_H, A_P, A_ARAW, A_STATS, A_M, A_MCAT, A_LOGITS, A_YPROB, A_YHAT, A_SLOG, A_SPROB, A_SHAT, A_AMAX_X, A_AMAX_H1, A_AMAX_H };
+static size_t arena_layout(const MilShape &s, int64_t *o) {
+    const size_t big = big_align(s.N), N = (size_t)s.N;
+    const size_t nb = toad_amax_floats(s.N) * sizeof(float);
+    Carver c;
+    o[A_H1] = c.take(N * kL * 4, big);
+    o[A_H] = c.take(N * kL * 4, big);
+    o[A_P] = c.take(N * 2 * s.D * 4, big);
+    o[A_ARAW] = c.take(N * kT * 4, big);
+    o[A_STATS] = c.take(kT * 2 * 4, 256);
+    o[A_M] = c.take(kT * kL * 4, 256);
+    o[A_MCAT] = c.take(kT * (kL + 1) * 4, 256);
+    o[A_LOGITS] = c.take((size_t)s.C * 4, 256);
+    o[A_YPROB] = c.take((size_t)s.C * 4, 256);
+    o[A_YHAT] = c.take(8, 256);
+    o[A_SLOG] = c.take(8, 256);
+    o[A_SPROB] = c.take(8, 256);
+    o[A_SHAT] = c.take(8, 256);
+    o[A_AMAX_X] = c.take(nb, 256);
+    o[A_AMAX_H1] = c.take(nb, 256);       // h1 / h arrays are adjacent: one memset zeroes both before the GEMM epilogues fill them
+    o[A_AMAX_H] = c.take(nb, 4);
+    return up(c.off, 256);
+}
+
+// ---- scratch ---------------------------------------------------------------------------------------------------------
+enum { W_1 = 0, W_2, W_AB, W_ABT, W_2T, W_1T, W_COUNT };      // split weight operands: forward x3, dgrad (transposed in place) x3
+struct Scratch {
+    float *slabs; void *gemm_ws; size_t gemm_ws_bytes;
+    unsigned short *planes[W_COUNT]; float *binv[W_COUNT];
+    float *t_abT, *t_2T, *t_1T;                               // materialised transposes (legacy path only)
+    void *pool_ws, *poolb_ws; size_t pool_ws_bytes, poolb_ws_bytes;
+    float *dlogits, *dsite, *dM, *loss;
+    float *amax_dP, *amax_dZ2, *amax_dZ1;
+    float *dP, *dZ2, *dZ1;
+    void *wgrad_ws; size_t wgrad_ws_bytes;
+    size_t total;
+};
+static Scratch scratch_layout(const MilShape &s, char *base) {
+    const size_t big = big_align(s.N), N = (size_t)s.N;
+    const int D2 = 2 * s.D;
+    const int wn[W_COUNT] = {kL, kL, D2, kL, kL, kL0}, wk[W_COUNT] = {kL0, kL, kL, D2, kL, kL};
+    Scratch r{};
+    Carver c;
+    auto P = [&](size_t off) { return base ? base + off : nullptr; };
+    r.gemm_ws_bytes = toad_linear_ws_bytes(s.N, kL0, kL0);            // slabs first, then room for the legacy per-op calls
+    r.gemm_ws = P(c.take(r.gemm_ws_bytes, big));
+    r.slabs = reinterpret_cast<float *>(r.gemm_ws);
+    for (int i = 0; i < W_COUNT; ++i) {
+        r.planes[i] = reinterpret_cast<unsigned short *>(P(c.take(h2_planes_bytes(wn[i], wk[i]), 4096)));
+        r.binv[i] = reinterpret_cast<float *>(P(c.take(h2_binv_bytes(wn[i]), 256)));
+    }
+    r.t_abT = reinterpret_cast<float *>(P(c.take((size_t)kL * D2 * 4, 256)));
+    r.t_2T = reinterpret_cast<float *>(P(c.take((size_t)kL * kL * 4, 256)));
+    r.t_1T = reinterpret_cast<float *>(P(c.take((size_t)kL0 * kL * 4, 256)));
+    r.pool_ws_bytes = toad_gated_pool_ws_bytes(s.N, kL, s.D, kT);
+    r.poolb_ws_bytes = toad_gated_pool_bwd_ws_bytes(s.N, kL, s.D, kT);
+    r.pool_ws = P(c.take(r.pool_ws_bytes, 4096));
+    r.poolb_ws = P(c.take(r.poolb_ws_bytes, 4096));
+    r.dlogits = reinterpret_cast<float *>(P(c.take((size_t)s.C * 4, 256)));
+    r.dsite = reinterpret_cast<float *>(P(c.take(8, 256)));
+    r.dM = reinterpret_cast<float *>(P(c.take(kT * kL * 4, 256)));
+    r.loss = reinterpret_cast<float *>(P(c.take(16, 256)));
+    const size_t nb = toad_amax_floats(s.N) * sizeof(float);
+    r.amax_dP = reinterpret_cast<float *>(P(c.take(nb, 256)));        // three adjacent arrays: one memset per backward
+    r.amax_dZ2 = reinterpret_cast<float *>(P(c.take(nb, 4)));
+    r.amax_dZ1 = reinterpret_cast<float *>(P(c.take(nb, 4)));
+    r.dP = reinterpret_cast<float *>(P(c.take(N * D2 * 4, big)));
+    r.dZ2 = reinterpret_cast<float *>(P(c.take(N * kL * 4, big)));
+    r.dZ1 = reinterpret_cast<float *>(P(c.take(N * kL * 4, big)));
+    size_t wg = toad_linear_wgrad_ws_bytes(s.N, D2, kL);
+    const size_t w2 = toad_linear_wgrad_ws_bytes(s.N, kL, kL), w1 = toad_linear_wgrad_ws_bytes(s.N, kL, kL0);
+    if (w2 > wg) wg = w2;
+    if (w1 > wg) wg = w1;
+    r.wgrad_ws_bytes = wg;
+    r.wgrad_ws = P(c.take(wg, big));
+    r.total = up(c.off, 256);
+    return r;
+}
+
+struct Fwd {                       // typed view of the arena
+    float *H1, *H, *P, *A_raw, *stats, *M, *Mcat, *logits, *yprob; int64_t *yhat; float *slog, *sprob; int64_t *shat;
+    float *amax_x, *amax_h1, *amax_h;
+};
+static Fwd arena_view(const MilShape &s, char *base) {
+    int64_t o[TOAD_MIL_ARENA_SLOTS];
+    arena_layout(s, o);
+    Fwd f;
+    f.H1 = (float *)(base + o[A_H1]); f.H = (float *)(base + o[A_H]); f.P = (float *)(base + o[A_P]); f.A_raw = (float *)(base + o[A_ARAW]);
+    f.stats = (float *)(base + o[A_STATS]); f.M = (float *)(base + o[A_M]); f.Mcat = (float *)(base + o[A_MCAT]);
+    f.logits = (float *)(base + o[A_LOGITS]); f.yprob = (float *)(base + o[A_YPROB]); f.yhat = (int64_t *)(base + o[A_YHAT]);
+    f.slog = (float *)(base + o[A_SLOG]); f.sprob = (float *)(base + o[A_SPROB]); f.shat = (int64_t *)(base + o[A_SHAT]);
+    f.amax_x = (float *)(base + o[A_AMAX_X]); f.amax_h1 = (float *)(base + o[A_AMAX_H1]); f.amax_h = (float *)(base + o[A_AMAX_H]);
+    return f;
+}
+
+struct Params { const float *w1, *b1, *w2, *b2, *wab, *bab, *wc, *bc, *wcls, *bcls, *wsite, *bsite; };
+static bool load_params(const float *const *p, Params &q, const char *what) {
+    for (int i = 0; i < 12; ++i) if (!p[i]) { set_error("%s: null parameter slot %d", what, i); return false; }
+    q = Params{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11]};
+    return true;
+}
+static bool shape_ok(const MilShape &s) { return s.N > 0 && s.N < INT32_MAX - 4096 && s.C > 0 && s.C <= 512 && (s.D == 256 || s.D == 384); }
+
+struct DropSeeds { uint64_t s1, s2, sa, sb; float mscale; };
+static DropSeeds drop_seeds(float drop_p, uint64_t seed) {          // must match toad_amd.functional.drop_seeds
+    const uint64_t G = 0x9E3779B97F4A7C15ull;
+    return DropSeeds{seed + 1 * G, seed + 2 * G, seed + 3 * G, seed + 4 * G, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f};
+}
+
+#define TOAD_TRY(call) do { const int rc_ = (call); if (rc_) return rc_; } while (0)
+
+// forward up to the pooled features: trunk, stacked attention GEMM, fused gated pool. `ev` records bench events (or nothing).
+template <typename Ev>
+static int forward_body(const MilShape &s, const Params &p, const float *X, const float *x_amax, float drop_p, uint64_t seed,
+                        bool attention_only, const Fwd &f, const Scratch &w, hipStream_t st, Ev ev, const char *what) {
+    const int64_t N = s.N;
+    const int D2 = 2 * s.D;
+    const DropSeeds ds = drop_seeds(drop_p, seed);
+    const bool h2 = h2_nt_ok(N, kL, kL0, kL0, kL);
+    const EpiScalars relu1{1, 1.f, make_drop(drop_p, ds.s1)}, relu2{1, 1.f, make_drop(drop_p, ds.s2)}, lin{0, 1.f, make_drop(0.f, 0)};
+    const H2Pool nopool{nullptr, nullptr, nullptr, 0};
+    if (h2) {
+        if (x_amax) (void)hipMemcpyAsync(f.amax_x, x_amax, toad_amax_floats(N) * sizeof(float), hipMemcpyDeviceToDevice, st);
+        else TOAD_TRY(launch_absmax(X, kL0, N, kL0, f.amax_x, st, what));
+        (void)hipMemsetAsync(f.amax_h1, 0, (size_t)((char *)f.amax_h - (char *)f.amax_h1) + toad_amax_floats(N) * sizeof(float), st);
+        const H2Operand ops[3] = {{p.w1, kL0, 1, kL, kL0, w.planes[W_1], w.binv[W_1]},
+                                  {p.w2, kL, 1, kL, kL, w.planes[W_2], w.binv[W_2]},
+                                  {p.wab, kL, 1, D2, kL, w.planes[W_AB], w.binv[W_AB]}};
+        TOAD_TRY(launch_split_h2(ops, 3, st, what));
+        ev(2); TOAD_TRY(launch_nt_h2(X, kL0, f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nopool, w.slabs, f.amax_h1, st, what)); ev(3);
+        ev(4); TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nopool, w.slabs, f.amax_h, st, what)); ev(5);
+        ev(6); TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nopool, w.slabs, nullptr, st, what)); ev(7);
+    } else {       // shapes beyond the persistent kernels' 32-bit offsets (> 1 M patches): the per-op entry points pick their kernels
+        ev(2); TOAD_TRY(toad_linear_act_fwd_f32(X, p.w1, p.b1, f.H1, N, kL0, kL, TOAD_ACT_RELU, drop_p, ds.s1, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(3);
+        ev(4); TOAD_TRY(toad_linear_act_fwd_f32(f.H1, p.w2, p.b2, f.H, N, kL, kL, TOAD_ACT_RELU, drop_p, ds.s2, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(5);
+        ev(6); TOAD_TRY(toad_linear_act_fwd_f32(f.H, p.wab, p.bab, f.P, N, kL, D2, TOAD_ACT_NONE, 0.f, 0, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(7);
+    }
+    if (attention_only) {
+        TOAD_TRY(toad_gated_pool_fwd_f32(f.P, f.P + s.D, D2, nullptr, p.wc, p.bc, f.A_raw, nullptr, nullptr, nullptr, 0, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st));
+        return TOAD_OK;
+    }
+    ev(0); TOAD_TRY(toad_gated_pool_fwd_f32(f.P, f.P + s.D, D2, f.H, p.wc, p.bc, f.A_raw, f.M, f.stats, w.pool_ws, w.pool_ws_bytes, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st)); ev(1);
+    return TOAD_OK;
+}
+
+// backward from dM (gradient of the pooled features) down to the trunk weights (and dX)
+template <typename Ev>
+static int backward_body(const MilShape &s, const Params &p, float *const *grads, float beta, const float *X, float drop_p, uint64_t seed,
+                         const Fwd &f, const float *dM, const float *dA_ext, float *dX, const Scratch &w, hipStream_t st, Ev ev, const char *what) {
+    const int64_t N = s.N;
+    const int D2 = 2 * s.D;
+    const DropSeeds ds = drop_seeds(drop_p, seed);
+    const bool h2 = h2_nt_ok(N, kL, kL0, kL0, kL);
+    const EpiScalars msk{0, ds.mscale, make_drop(0.f, 0)}, plain{0, 1.f, make_drop(0.f, 0)};
+    const H2Pool nopool{nullptr, nullptr, nullptr, 0};
+    if (h2) {
+        (void)hipMemsetAsync(w.amax_dP, 0, (size_t)((char *)w.amax_dZ1 - (char *)w.amax_dP) + toad_amax_floats(N) * sizeof(float), st);
+        // dgrad operands B[n,k] = W[k,n], read transposed in place: no transpose launches
+        const H2Operand ops[3] = {{p.wab, 1, kL, kL, D2, w.planes[W_ABT], w.binv[W_ABT]},
+                                  {p.w2, 1, kL, kL, kL, w.planes[W_2T], w.binv[W_2T]},
+                                  {p.w1, 1, kL0, kL0, kL, w.planes[W_1T], w.binv[W_1T]}};
+        TOAD_TRY(launch_split_h2(ops, dX ? 3 : 2, st, what));
+        TOAD_TRY(toad_gated_pool_bwd_f32(f.P, f.P + s.D, D2, f.H, p.wc, f.A_raw, f.stats, f.M, dM, dA_ext, w.dP, w.dP + s.D, D2, nullptr,
+                                         grads[6], grads[7], beta, w.amax_dP, w.poolb_ws, w.poolb_ws_bytes, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st));
+        ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what)); ev(9);
+        // dZ2 = (dP Wab + dH_pool) * (H > 0): the pooling gradient dH_pool is recomputed in the epilogue from A_raw, stats, dM
+        ev(10); TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, nullptr, f.H,
+                                      H2Pool{f.A_raw, f.stats, dM, kT}, w.slabs, w.amax_dZ2, st, what)); ev(11);
+        ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws, st, what)); ev(13);
+        ev(14); TOAD_TRY(launch_nt_h2(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, nopool,
+                                      w.slabs, w.amax_dZ1, st, what)); ev(15);
+        ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, X, f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws, st, what)); ev(17);
+        if (dX) TOAD_TRY(launch_nt_h2(w.dZ1, kL, w.amax_dZ1, w.planes[W_1T], w.binv[W_1T], dX, kL0, N, kL0, kL, nullptr, plain, nullptr, nullptr, nopool,
+                                      w.slabs, nullptr, st, what));
+        return TOAD_OK;
+    }
+    // legacy sequence (per-op entry points, materialised dH_pool in the dZ2 buffer, explicit transposes)
+    float *dH = w.dZ2;
+    TOAD_TRY(toad_gated_pool_bwd_f32(f.P, f.P + s.D, D2, f.H, p.wc, f.A_raw, f.stats, f.M, dM, dA_ext, w.dP, w.dP + s.D, D2, dH, grads[6], grads[7],
+                                     beta, nullptr, w.poolb_ws, w.poolb_ws_bytes, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st));
+    ev(8); TOAD_TRY(toad_linear_wgrad_f32(w.dP, f.H, grads[4], grads[5], N, D2, kL, beta, nullptr, nullptr, w.wgrad_ws, w.wgrad_ws_bytes, st)); ev(9);
+    TOAD_TRY(toad_transpose_f32(p.wab, w.t_abT, D2, kL, st));
+    ev(10); TOAD_TRY(toad_linear_dgrad_f32(w.dP, w.t_abT, dH, f.H, ds.mscale, dH, N, D2, kL, nullptr, nullptr, nullptr, 0, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(11);
+    ev(12); TOAD_TRY(toad_linear_wgrad_f32(dH, f.H1, grads[2], grads[3], N, kL, kL, beta, nullptr, nullptr, w.wgrad_ws, w.wgrad_ws_bytes, st)); ev(13);
+    TOAD_TRY(toad_transpose_f32(p.w2, w.t_2T, kL, kL, st));
+    ev(14); TOAD_TRY(toad_linear_dgrad_f32(dH, w.t_2T, nullptr, f.H1, ds.mscale, w.dZ1, N, kL, kL, nullptr, nullptr, nullptr, 0, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(15);
+    ev(16); TOAD_TRY(toad_linear_wgrad_f32(w.dZ1, X, grads[0], grads[1], N, kL, kL0, beta, nullptr, nullptr, w.wgrad_ws, w.wgrad_ws_bytes, st)); ev(17);
+    if (dX) {
+        TOAD_TRY(toad_transpose_f32(p.w1, w.t_1T, kL, kL0, st));
+        TOAD_TRY(toad_linear_dgrad_f32(w.dZ1, w.t_1T, nullptr, nullptr, 1.f, dX, N, kL, kL0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st));
+    }
+    return TOAD_OK;
+}
+
+struct NoEvents { void operator()(int) const {} };
+struct StreamEvents {
+    void **events; hipStream_t st;
+    void operator()(int i) const { if (events && events[i]) (void)hipEventRecord((hipEvent_t)events[i], st); }
+};
 
 }  // namespace toad
 
 using namespace toad;
 
+extern "C" size_t toad_mil_arena_bytes(int64_t N, int C, int D) {
+    const MilShape s{N, C, D};
+    if (!shape_ok(s)) return 0;
+    int64_t o[TOAD_MIL_ARENA_SLOTS];
+    return arena_layout(s, o) + big_align(N);          // slack to align the base
+}
+extern "C" int toad_mil_arena_layout(int64_t N, int C, int D, int64_t *offsets) {
+    const MilShape s{N, C, D};
+    if (!shape_ok(s) || !offsets) { set_error("toad_mil_arena_layout: bad shape"); return TOAD_ESHAPE; }
+    arena_layout(s, offsets);
+    return TOAD_OK;
+}
+extern "C" size_t toad_mil_scratch_bytes(int64_t N, int C, int D) {
+    const MilShape s{N, C, D};
+    if (!shape_ok(s)) return 0;
+    return scratch_layout(s, nullptr).total + big_align(N);
+}
+extern "C" size_t toad_mil_buffer_align(int64_t N) { return big_align(N); }
 extern "C" size_t toad_mil_step_ws_bytes(int64_t N, int C, int D) {
-    if (N <= 0 || C <= 0 || (D != 256 && D != 384)) return 0;
-    const int L0 = kDims.L0, L = kDims.L, T = kDims.T;
-    size_t b = 0;
-    auto add = [&](size_t n) { b += align256(n); };
-    add((size_t)N * L * 4);            // H1
-    add((size_t)N * L * 4);            // H
-    add((size_t)N * 2 * D * 4);        // P
-    add((size_t)N * T * 4);            // A_raw
-    add(T * 2 * 4); add(T * L * 4); add(T * (L + 1) * 4);      // stats, M, Mcat
-    add(C * 4); add(C * 4); add(8); add(8); add(8); add(8); add(8);   // logits, Y_prob, Y_hat, site_logits, site_prob, site_hat, (pad)
-    add(C * 4); add(8); add(T * L * 4);                          // dlogits, dsite, dM
-    add((size_t)N * 2 * D * 4);        // dP
-    add((size_t)N * L * 4);            // dH -> dZ2 (in place)
-    add((size_t)N * L * 4);            // dZ1
-    add((size_t)L * 2 * D * 4); add((size_t)L * L * 4);          // WabT, W2T
-    add(toad_gated_pool_ws_bytes(N, L, D, T));
-    add(toad_gated_pool_bwd_ws_bytes(N, L, D, T));
-    add(toad_linear_ws_bytes(N, L, L0));
-    size_t wg = toad_linear_wgrad_ws_bytes(N, 2 * D, L);
-    size_t w2 = toad_linear_wgrad_ws_bytes(N, L, L), w1 = toad_linear_wgrad_ws_bytes(N, L, L0);
-    if (w2 > wg) wg = w2;
-    if (w1 > wg) wg = w1;
-    add(wg);
-    (void)L0;
-    return b + ((size_t)1 << 21);
+    const size_t a = toad_mil_arena_bytes(N, C, D), b = toad_mil_scratch_bytes(N, C, D);
+    return (a && b) ? a + b : 0;
+}
+
+// The arena base is used as given when it is aligned to the bag's buffer granularity, else rounded up inside the allocation.
+// toad_mil_arena_layout offsets are relative to that aligned base: callers pass an aligned pointer (torch allocations of this
+// size are 2 MiB aligned) or compute the same round-up.
+static char *align_base(void *p, int64_t N) {
+    const uintptr_t a = big_align(N);
+    return reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(p) + a - 1) & ~(a - 1));
+}
+
+extern "C" int toad_mil_fwd_f32(const float *const *params, const float *X, const float *sex, int64_t N, int C, int D, float drop_p,
+                                 uint64_t seed, const float *x_amax, int attention_only, void *arena, size_t arena_bytes,
+                                 void *scratch, size_t scratch_bytes, void *stream) {
+    const char *what = "toad_mil_fwd_f32";
+    const MilShape s{N, C, D};
+    if (!params || !X || !arena || !scratch || (!attention_only && !sex)) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (!shape_ok(s)) { set_error("%s: unsupported shape N=%lld C=%d D=%d", what, (long long)N, C, D); return TOAD_ESHAPE; }
+    if (!(drop_p >= 0.f && drop_p < 1.f)) { set_error("%s: drop_p must be in [0,1)", what); return TOAD_EINVAL; }
+    if (!aligned16(X)) { set_error("%s: X must be 16-byte aligned", what); return TOAD_EALIGN; }
+    char *ab = align_base(arena, N), *sb = align_base(scratch, N);
+    int64_t o[TOAD_MIL_ARENA_SLOTS];
+    if ((size_t)(ab - (char *)arena) + arena_layout(s, o) > arena_bytes) { set_error("%s: arena too small", what); return TOAD_EWORKSPACE; }
+    const Scratch w = scratch_layout(s, sb);
+    if ((size_t)(sb - (char *)scratch) + w.total > scratch_bytes) { set_error("%s: scratch too small", what); return TOAD_EWORKSPACE; }
+    Params p;
+    if (!load_params(params, p, what)) return TOAD_EINVAL;
+    const Fwd f = arena_view(s, ab);
+    hipStream_t st = (hipStream_t)stream;
+    TOAD_TRY(forward_body(s, p, X, x_amax, drop_p, seed, attention_only != 0, f, w, st, NoEvents{}, what));
+    if (attention_only) return TOAD_OK;
+    return toad_heads_fwd_f32(f.M, sex, p.wcls, p.bcls, p.wsite, p.bsite, f.Mcat, f.logits, f.yprob, f.yhat, f.slog, f.sprob, f.shat, kL, C, st);
+}
+
+extern "C" int toad_mil_bwd_f32(const float *const *params, float *const *grads, float beta, const float *X, int64_t N, int C, int D,
+                                 float drop_p, uint64_t seed, const void *arena, size_t arena_bytes, const float *dlogits,
+                                 const float *dsite, const float *dA_ext, const float *dMcat_ext, float *dX, float *dsex,
+                                 void *scratch, size_t scratch_bytes, void *stream) {
+    const char *what = "toad_mil_bwd_f32";
+    const MilShape s{N, C, D};
+    if (!params || !grads || !X || !arena || !scratch || !dlogits || !dsite) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (!shape_ok(s)) { set_error("%s: unsupported shape N=%lld C=%d D=%d", what, (long long)N, C, D); return TOAD_ESHAPE; }
+    if (dX && !aligned16(dX)) { set_error("%s: dX must be 16-byte aligned", what); return TOAD_EALIGN; }
+    char *ab = align_base(const_cast<void *>(arena), N), *sb = align_base(scratch, N);
+    int64_t o[TOAD_MIL_ARENA_SLOTS];
+    if ((size_t)(ab - (const char *)arena) + arena_layout(s, o) > arena_bytes) { set_error("%s: arena too small", what); return TOAD_EWORKSPACE; }
+    const Scratch w = scratch_layout(s, sb);
+    if ((size_t)(sb - (char *)scratch) + w.total > scratch_bytes) { set_error("%s: scratch too small", what); return TOAD_EWORKSPACE; }
+    Params p;
+    if (!load_params(params, p, what)) return TOAD_EINVAL;
+    for (int i = 0; i < 12; ++i) if (!grads[i]) { set_error("%s: null gradient slot %d", what, i); return TOAD_EINVAL; }
+    const Fwd f = arena_view(s, ab);
+    hipStream_t st = (hipStream_t)stream;
+    TOAD_TRY(toad_heads_bwd_f32(f.Mcat, dlogits, dsite, p.wcls, p.wsite, dMcat_ext, grads[8], grads[9], grads[10], grads[11], w.dM, dsex, beta, kL, C, st));
+    return backward_body(s, p, grads, beta, X, drop_p, seed, f, w.dM, dA_ext, dX, w, st, NoEvents{}, what);
 }
 
 // events: NULL, or 18 hipEvent_t: [0,1] bracket the fused pool forward, [2+2i, 3+2i] bracket GEMM call i
 // (fwd1, fwd2, fwd_ab, wgrad_ab, dgrad_ab, wgrad_2, dgrad_2, wgrad_1) - for bench.py's roofline figures.
 extern "C" int toad_mil_step_f32(const float *const *params, float *const *grads, float beta, const float *X,
                                   const float *sex, const int64_t *label, const int64_t *site, float w_cls,
-                                  float w_site, int64_t N, int C, int D, float drop_p, uint64_t seed,
+                                  float w_site, int64_t N, int C, int D, float drop_p, uint64_t seed, const float *x_amax,
                                   float *loss_out, float *logits_out, float *site_logits_out, void *ws,
                                   size_t ws_bytes, void **events, void *stream) {
     const char *what = "toad_mil_step_f32";
+    const MilShape s{N, C, D};
     if (!params || !grads || !X || !sex || !label || !site || !loss_out || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
-    if (ws_bytes < toad_mil_step_ws_bytes(N, C, D) || toad_mil_step_ws_bytes(N, C, D) == 0) { set_error("%s: workspace too small or bad shape", what); return TOAD_EWORKSPACE; }
-    if (!aligned16(ws)) { set_error("%s: workspace must be 16-byte aligned", what); return TOAD_EALIGN; }
-    const int L0 = kDims.L0, L = kDims.L, T = kDims.T;
-    // parameter slots (same order for params and grads): w1 b1 w2 b2 wab bab wc bc wcls bcls wsite bsite
-    const float *w1 = params[0], *b1 = params[1], *w2 = params[2], *b2 = params[3], *wab = params[4], *bab = params[5],
-                *wc = params[6], *bc = params[7], *wcls = params[8], *bcls = params[9], *wsite = params[10], *bsite = params[11];
-    for (int i = 0; i < 12; ++i) if (!params[i] || !grads[i]) { set_error("%s: null parameter/gradient slot %d", what, i); return TOAD_EINVAL; }
+    if (!shape_ok(s)) { set_error("%s: unsupported shape N=%lld C=%d D=%d", what, (long long)N, C, D); return TOAD_ESHAPE; }
+    if (!(drop_p >= 0.f && drop_p < 1.f)) { set_error("%s: drop_p must be in [0,1)", what); return TOAD_EINVAL; }
+    if (!aligned16(X)) { set_error("%s: X must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (ws_bytes < toad_mil_step_ws_bytes(N, C, D)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
+    Params p;
+    if (!load_params(params, p, what)) return TOAD_EINVAL;
+    for (int i = 0; i < 12; ++i) if (!grads[i]) { set_error("%s: null gradient slot %d", what, i); return TOAD_EINVAL; }
+    char *ab = align_base(ws, N);
+    int64_t o[TOAD_MIL_ARENA_SLOTS];
+    char *sb = align_base(ab + arena_layout(s, o), N);
+    const Fwd f = arena_view(s, ab);
+    const Scratch w = scratch_layout(s, sb);
     hipStream_t st = (hipStream_t)stream;
-    Arena a{reinterpret_cast<char *>(ws), 0, ws_bytes};
-    a.off = align256(reinterpret_cast<uintptr_t>(ws)) - reinterpret_cast<uintptr_t>(ws);     // 2 MiB-align the first buffer
-    float *H1 = a.take<float>((size_t)N * L), *H = a.take<float>((size_t)N * L), *P = a.take<float>((size_t)N * 2 * D);
-    float *A_raw = a.take<float>((size_t)N * T), *stats = a.take<float>(T * 2), *M = a.take<float>(T * L), *Mcat = a.take<float>(T * (L + 1));
-    float *logits = a.take<float>(C), *yprob = a.take<float>(C);
-    int64_t *yhat = a.take<int64_t>(1);
-    float *slog = a.take<float>(2), *sprob = a.take<float>(2);
-    int64_t *shat = a.take<int64_t>(1);
-    (void)a.take<float>(2);
-    float *dlogits = a.take<float>(C), *dsite = a.take<float>(2), *dM = a.take<float>(T * L);
-    float *dP = a.take<float>((size_t)N * 2 * D), *dH = a.take<float>((size_t)N * L), *dZ1 = a.take<float>((size_t)N * L);
-    float *WabT = a.take<float>((size_t)L * 2 * D), *W2T = a.take<float>((size_t)L * L);
-    const size_t pws = toad_gated_pool_ws_bytes(N, L, D, T), pbws = toad_gated_pool_bwd_ws_bytes(N, L, D, T);
-    void *pool_ws = a.take<char>(pws), *poolb_ws = a.take<char>(pbws);
-    const size_t gws = toad_linear_ws_bytes(N, L, L0);
-    void *gemm_ws = a.take<char>(gws);
-    void *wgrad_ws = a.base + a.off;
-    const size_t wgrad_cap = ws_bytes - a.off;
-
-    auto ev = [&](int i) { if (events && events[i]) (void)hipEventRecord((hipEvent_t)events[i], st); };
-    // four dropout streams from one seed (must match toad_amd.functional.drop_seeds)
-    const uint64_t G = 0x9E3779B97F4A7C15ull;
-    const uint64_t s1 = seed + 1 * G, s2 = seed + 2 * G, sa = seed + 3 * G, sb = seed + 4 * G;
-    const float mscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    int rc;
-#define TOAD_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
-    // ---- forward
-    ev(2); TOAD_TRY(toad_linear_act_fwd_f32(X, w1, b1, H1, N, L0, L, TOAD_ACT_RELU, drop_p, s1, gemm_ws, gws, st)); ev(3);
-    ev(4); TOAD_TRY(toad_linear_act_fwd_f32(H1, w2, b2, H, N, L, L, TOAD_ACT_RELU, drop_p, s2, gemm_ws, gws, st)); ev(5);
-    ev(6); TOAD_TRY(toad_linear_act_fwd_f32(H, wab, bab, P, N, L, 2 * D, TOAD_ACT_NONE, 0.f, 0, gemm_ws, gws, st)); ev(7);
-    ev(0); TOAD_TRY(toad_gated_pool_fwd_f32(P, P + D, 2 * D, H, wc, bc, A_raw, M, stats, pool_ws, pws, N, L, D, T, drop_p, sa, sb, st)); ev(1);
-    TOAD_TRY(toad_heads_fwd_f32(M, sex, wcls, bcls, wsite, bsite, Mcat, logits, yprob, yhat, slog, sprob, shat, L, C, st));
-    TOAD_TRY(toad_mtl_ce_fwd_bwd_f32(logits, slog, label, site, w_cls, w_site, loss_out, dlogits, dsite, C, st));
-    if (logits_out) (void)hipMemcpyAsync(logits_out, logits, C * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (site_logits_out) (void)hipMemcpyAsync(site_logits_out, slog, 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
-    // ---- backward
-    TOAD_TRY(toad_heads_bwd_f32(Mcat, dlogits, dsite, wcls, wsite, nullptr, grads[8], grads[9], grads[10], grads[11], dM, beta, L, C, st));
-    TOAD_TRY(toad_gated_pool_bwd_f32(P, P + D, 2 * D, H, wc, A_raw, stats, M, dM, nullptr, dP, dP + D, 2 * D, dH, grads[6], grads[7],
-                                     beta, poolb_ws, pbws, N, L, D, T, drop_p, sa, sb, st));
-    ev(8); TOAD_TRY(toad_linear_wgrad_f32(dP, H, grads[4], grads[5], N, 2 * D, L, beta, wgrad_ws, wgrad_cap, st)); ev(9);
-    TOAD_TRY(toad_transpose_f32(wab, WabT, 2 * D, L, st));
-    ev(10); TOAD_TRY(toad_linear_dgrad_f32(dP, WabT, dH, H, mscale, dH, N, 2 * D, L, gemm_ws, gws, st)); ev(11);
-    ev(12); TOAD_TRY(toad_linear_wgrad_f32(dH, H1, grads[2], grads[3], N, L, L, beta, wgrad_ws, wgrad_cap, st)); ev(13);
-    TOAD_TRY(toad_transpose_f32(w2, W2T, L, L, st));
-    ev(14); TOAD_TRY(toad_linear_dgrad_f32(dH, W2T, nullptr, H1, mscale, dZ1, N, L, L, gemm_ws, gws, st)); ev(15);
-    ev(16); TOAD_TRY(toad_linear_wgrad_f32(dZ1, X, grads[0], grads[1], N, L, L0, beta, wgrad_ws, wgrad_cap, st)); ev(17);
-#undef TOAD_TRY
-    return TOAD_OK;
+    const StreamEvents ev{events, st};
+    TOAD_TRY(forward_body(s, p, X, x_amax, drop_p, seed, false, f, w, st, ev, what));
+    // heads + weighted CE + heads backward: one single-workgroup launch
+    TOAD_TRY(toad_heads_ce_fused_f32(f.M, sex, p.wcls, p.bcls, p.wsite, p.bsite, label, site, w_cls, w_site, f.Mcat, f.logits, f.yprob, f.yhat,
+                                     f.slog, f.sprob, f.shat, loss_out, nullptr, nullptr, grads[8], grads[9], grads[10], grads[11], w.dM, beta, kL, C, st));
+    if (logits_out) (void)hipMemcpyAsync(logits_out, f.logits, C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (site_logits_out) (void)hipMemcpyAsync(site_logits_out, f.slog, 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    return backward_body(s, p, grads, beta, X, drop_p, seed, f, w.dM, nullptr, nullptr, w, st, ev, what);
 }

@@ -92,11 +92,18 @@ class SlideShardedDP:
         # zero), so the update is a single elementwise launch instead of a 14-tensor multi-tensor apply
         self.flat_param = torch.nn.Parameter(self.flat, requires_grad=True)
         self.flat_param.grad = self.flat_grad
-        # optimizer_factory == "adam" (or a dict of FlatAdam kwargs) selects the one-launch HIP Adam;
-        # a callable receives [flat_param] and may return any torch optimiser.
-        if optimizer_factory == "adam" or isinstance(optimizer_factory, dict):
+        # optimizer_factory == "adam" / "sgd" (or a dict of FlatAdam / FlatSGD kwargs, {"opt": "sgd", ...} for SGD) selects the
+        # one-launch HIP optimisers (get_optim's two branches, utils/utils.py:63-70); a callable receives [flat_param] and may
+        # return any torch optimiser.
+        if optimizer_factory == "sgd" or (isinstance(optimizer_factory, dict) and optimizer_factory.get("opt") == "sgd"):
+            from .optim import FlatSGD
+            kw = {k: v for k, v in optimizer_factory.items() if k != "opt"} if isinstance(optimizer_factory, dict) else {}
+            self._flat_adam = FlatSGD(self.flat, **kw)          # same interface: .step(flat_grad)
+            self.optimizer = None
+        elif optimizer_factory == "adam" or isinstance(optimizer_factory, dict):
             from .optim import FlatAdam
-            self._flat_adam = FlatAdam(self.flat, **(optimizer_factory if isinstance(optimizer_factory, dict) else {}))
+            kw = {k: v for k, v in optimizer_factory.items() if k != "opt"} if isinstance(optimizer_factory, dict) else {}
+            self._flat_adam = FlatAdam(self.flat, **kw)
             self.optimizer = None
         else:
             self._flat_adam = None
@@ -106,9 +113,18 @@ class SlideShardedDP:
     def zero_grad(self):
         self.flat_grad.zero_()
 
+    def _check_flat(self):
+        """The optimiser, the all-reduce and the gradient views were bound to the flat buffer at construction. model.to(),
+        a deepcopy or a load that re-homes parameters makes the model re-flatten into a NEW buffer; training on would then
+        update a buffer the forward no longer reads (a silent no-op), so that is an error here."""
+        if self.model.flat_parameters() is not self.flat:
+            raise RuntimeError("SlideShardedDP: the model's flat parameter buffer was replaced after construction "
+                               "(model.to()/deepcopy/re-flatten); build a new SlideShardedDP for the moved model")
+
     def accumulate(self, slides: Sequence[Slide], global_slides: int, overwrite: bool = True):
         """grads (+)= sum over ``slides`` of d(loss)/d(params) / global_slides. With ``overwrite`` the
         first slide is written with beta = 0, which replaces a zeroing pass over the bucket."""
+        self._check_flat()
         if not slides:
             if overwrite:
                 self.zero_grad()

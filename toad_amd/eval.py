@@ -28,7 +28,15 @@ def initiate_model(args, ckpt_path: Optional[str] = None) -> TOAD_fc_mtl_concat:
     model.relocate()
     if ckpt_path is not None:
         ckpt = torch.load(ckpt_path, map_location="cpu")
-        model.load_state_dict(ckpt, strict=False)
+        # non-strict like the reference (eval_utils:28-29), but never silently partial: DataParallel-era keys
+        # (``attention_net.module.*``) are renamed by the model's loader, and anything still missing is an error
+        res = model.load_state_dict(ckpt, strict=False)
+        if res.missing_keys:
+            raise RuntimeError(f"{ckpt_path}: checkpoint lacks {len(res.missing_keys)} model tensors "
+                               f"(e.g. {res.missing_keys[:3]}); refusing to evaluate a partly random model")
+        if res.unexpected_keys:
+            import warnings
+            warnings.warn(f"{ckpt_path}: ignoring {len(res.unexpected_keys)} unexpected keys, e.g. {res.unexpected_keys[:3]}")
     model.eval()
     return model
 

@@ -203,6 +203,20 @@ class TOAD_fc_mtl_concat(nn.Module):
         w.update(self._views)
         return w
 
+    # ---- checkpoints ----------------------------------------------------------------------
+    _DP_INFIX = "attention_net.module."
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """Checkpoints written by a multi-GPU REFERENCE run carry nn.DataParallel's ``module.`` infix
+        (models/model_toad.py:79-81 wraps attention_net whenever device_count() > 1, so its keys are
+        ``attention_net.module.0.weight`` ...). This build never wraps, so those keys are renamed on load;
+        without it eval_utils' non-strict load (eval_utils_mtl_concat.py:28-29) would silently leave the
+        whole attention branch at its random initialisation."""
+        infix = prefix + self._DP_INFIX
+        for k in [k for k in state_dict if k.startswith(infix)]:
+            state_dict[prefix + "attention_net." + k[len(infix):]] = state_dict.pop(k)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     # ---- reference API --------------------------------------------------------------------
     def relocate(self):
         """Reference: models/model_toad.py:77-88. Places the model on the current HIP device.
@@ -222,7 +236,11 @@ class TOAD_fc_mtl_concat(nn.Module):
         h = h.contiguous()
         if attention_only:
             with torch.no_grad():
-                a_raw = F_.attention_scores({k: v.detach() for k, v in w.items()}, h, drop_p, seed)
+                wd = {k: v.detach() for k, v in w.items()}
+                if h.shape[0] == 0:
+                    a_raw = F_.attention_scores(wd, h, drop_p, seed)
+                else:                                             # trunk + scores in one library call, no pooling / heads
+                    a_raw = ops.mil_fwd(wd, h, None, drop_p, seed, attention_only=True).view("a_raw", (h.shape[0], 2))
             return a_raw.t()[0]                                   # model_toad.py:92-94: raw task-0 scores, [N]
         _require_cuda(sex, "sex")
         sex = sex.to(torch.float32).reshape(1).contiguous()

@@ -72,13 +72,50 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _ws(nbytes: int, device) -> torch.Tensor:
-    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+# Per-op workspaces are scratch: one growing buffer per (device, stream) instead of one allocation per call. Work on a
+# stream is ordered, so consecutive ops of that stream can share it; different streams (two models training side by side)
+# get different buffers.
+_WS_CACHE = {}
 
 
-def linear_act_fwd(x, w, b, act: int, out: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
-    """Y = dropout_p(act(X W^T + b)); X [M,K], W [N,K], b [N] or None. drop_p = 0 disables dropout."""
-    _chk(x, "x"); _chk(w, "w"); _chk(b, "b", allow_none=True)
+def _ws(nbytes: int, device, slot: str = "op") -> torch.Tensor:
+    nbytes = max(int(nbytes), 16)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(), slot)
+    buf = _WS_CACHE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes + (nbytes >> 3), dtype=torch.uint8, device=device)      # 12 % headroom: bags vary in length
+        _WS_CACHE[key] = buf
+    return buf
+
+
+def release_workspaces() -> None:
+    """Drop every cached workspace (they are re-created on demand)."""
+    _WS_CACHE.clear()
+
+
+def amax_floats(rows: int) -> int:
+    return int(_lib.load().toad_amax_floats(int(rows)))
+
+
+def absmax_rows256(x: torch.Tensor) -> torch.Tensor:
+    """abs-max array of x [M,K]: one float per block of 256 rows (the operand scales of the fp16 two-piece GEMMs)."""
+    _chk(x, "x")
+    m, k = x.shape
+    out = torch.empty((amax_floats(m),), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().toad_absmax_rows256_f32(_p(x), m, k, _p(out), _stream()), "toad_absmax_rows256_f32")
+    return out
+
+
+def h2_ok(m: int, n: int, k: int) -> bool:
+    """True when the persistent fp16 two-piece kernel serves an [m,k] x [n,k]^T product."""
+    return bool(_lib.load().toad_linear_h2_ok(int(m), int(n), int(k)))
+
+
+def linear_act_fwd(x, w, b, act: int, out: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0,
+                   x_amax: Optional[torch.Tensor] = None, want_amax: bool = False):
+    """Y = dropout_p(act(X W^T + b)); X [M,K], W [N,K], b [N] or None. drop_p = 0 disables dropout.
+    x_amax: abs-max array of X (else measured inside). want_amax: also return the abs-max array of Y -> (Y, y_amax)."""
+    _chk(x, "x"); _chk(w, "w"); _chk(b, "b", allow_none=True); _chk(x_amax, "x_amax", allow_none=True)
     m, k = x.shape
     n, k2 = w.shape
     if k != k2 or (b is not None and b.numel() != n):
@@ -86,11 +123,12 @@ def linear_act_fwd(x, w, b, act: int, out: Optional[torch.Tensor] = None, drop_p
     y = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=x.device)
     _chk(y, "out")
     lib = _lib.load()
+    y_amax = torch.empty((amax_floats(m),), dtype=torch.float32, device=x.device) if want_amax else None
     ws = _ws(lib.toad_linear_ws_bytes(m, n, k), x.device)
     with _timed("gemm_fwd"):
         _lib.check(lib.toad_linear_act_fwd_f32(_p(x), _p(w), _p(b), _p(y), m, k, n, act, float(drop_p), int(drop_seed),
-                                               _p(ws), ws.numel(), _stream()), "toad_linear_act_fwd_f32")
-    return y
+                                               _p(x_amax), _p(y_amax), _p(ws), ws.numel(), _stream()), "toad_linear_act_fwd_f32")
+    return (y, y_amax) if want_amax else y
 
 
 def transpose(w: torch.Tensor) -> torch.Tensor:
@@ -101,9 +139,13 @@ def transpose(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def linear_dgrad(dy, wt, addend=None, relu_src=None, out: Optional[torch.Tensor] = None, mask_scale: float = 1.0) -> torch.Tensor:
-    """dX = (dY W + addend) * (relu_src > 0) * mask_scale; dY [M,N], wt = W^T [K,N]."""
+def linear_dgrad(dy, wt, addend=None, relu_src=None, out: Optional[torch.Tensor] = None, mask_scale: float = 1.0,
+                 pool=None, dy_amax: Optional[torch.Tensor] = None, want_amax: bool = False):
+    """dX = (dY W + addend + pool) * (relu_src > 0) * mask_scale; dY [M,N], wt = W^T [K,N].
+    pool = (A_raw [M,T], stats [T,2], dM [T,K]): the attention-pooling gradient sum_t softmax(A_raw)[:,t] dM[t,:], recomputed in
+    the epilogue instead of read from an [M,K] buffer (needs h2_ok(M, K, N))."""
     _chk(dy, "dy"); _chk(wt, "wt"); _chk(addend, "addend", allow_none=True); _chk(relu_src, "relu_src", allow_none=True)
+    _chk(dy_amax, "dy_amax", allow_none=True)
     m, n = dy.shape
     k, n2 = wt.shape
     if n != n2:
@@ -113,18 +155,29 @@ def linear_dgrad(dy, wt, addend=None, relu_src=None, out: Optional[torch.Tensor]
     for t, nm in ((addend, "addend"), (relu_src, "relu_src"), (dx, "out")):
         if t is not None and tuple(t.shape) != (m, k):
             raise ValueError(f"linear_dgrad: {nm} must be [{m},{k}]")
+    pa = ps = pd = None
+    pt = 0
+    if pool is not None:
+        pa, ps, pd = pool
+        _chk(pa, "pool A_raw"); _chk(ps, "pool stats"); _chk(pd, "pool dM")
+        pt = pa.shape[1]
+        if pa.shape[0] != m or tuple(ps.shape) != (pt, 2) or tuple(pd.shape) != (pt, k):
+            raise ValueError("linear_dgrad: pooling-addend shapes must be A_raw [M,T], stats [T,2], dM [T,K]")
     lib = _lib.load()
+    dx_amax = torch.empty((amax_floats(m),), dtype=torch.float32, device=dy.device) if want_amax else None
     ws = _ws(lib.toad_linear_ws_bytes(m, k, n), dy.device)
     with _timed("gemm_dgrad"):
         _lib.check(lib.toad_linear_dgrad_f32(_p(dy), _p(wt), _p(addend), _p(relu_src), float(mask_scale), _p(dx), m, n, k,
-                                             _p(ws), ws.numel(), _stream()), "toad_linear_dgrad_f32")
-    return dx
+                                             _p(pa), _p(ps), _p(pd), pt, _p(dy_amax), _p(dx_amax), _p(ws), ws.numel(), _stream()),
+                   "toad_linear_dgrad_f32")
+    return (dx, dx_amax) if want_amax else dx
 
 
 def linear_wgrad(dy, x, dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None,
-                 beta: float = 0.0, want_db: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """dW = beta*dW + dY^T X; db = beta*db + colsum(dY)."""
-    _chk(dy, "dy"); _chk(x, "x")
+                 beta: float = 0.0, want_db: bool = True, dy_amax: Optional[torch.Tensor] = None,
+                 x_amax: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """dW = beta*dW + dY^T X; db = beta*db + colsum(dY). dy_amax / x_amax: abs-max arrays of the operands (else measured)."""
+    _chk(dy, "dy"); _chk(x, "x"); _chk(dy_amax, "dy_amax", allow_none=True); _chk(x_amax, "x_amax", allow_none=True)
     m, n = dy.shape
     m2, k = x.shape
     if m != m2:
@@ -136,10 +189,10 @@ def linear_wgrad(dy, x, dw: Optional[torch.Tensor] = None, db: Optional[torch.Te
     _chk(dw, "dw"); _chk(db, "db", allow_none=True)
     lib = _lib.load()
     nbytes = lib.toad_linear_wgrad_ws_bytes(m, n, k)
-    ws = _ws(nbytes, dy.device)
+    ws = _ws(nbytes, dy.device, "wgrad")
     with _timed("gemm_wgrad"):
-        _lib.check(lib.toad_linear_wgrad_f32(_p(dy), _p(x), _p(dw), _p(db), m, n, k, float(beta), _p(ws), ws.numel(), _stream()),
-                   "toad_linear_wgrad_f32")
+        _lib.check(lib.toad_linear_wgrad_f32(_p(dy), _p(x), _p(dw), _p(db), m, n, k, float(beta), _p(dy_amax), _p(x_amax),
+                                             _p(ws), ws.numel(), _stream()), "toad_linear_wgrad_f32")
     return dw, db
 
 
@@ -171,7 +224,7 @@ def gated_pool_fwd(p: torch.Tensor, d: int, h: Optional[torch.Tensor], wc, bc, d
         raise ValueError("gated_pool_fwd: h rows != p rows")
     m = torch.empty((t, l), dtype=torch.float32, device=p.device)
     stats = torch.empty((t, 2), dtype=torch.float32, device=p.device)
-    ws = _ws(lib.toad_gated_pool_ws_bytes(n, l, d, t), p.device)
+    ws = _ws(lib.toad_gated_pool_ws_bytes(n, l, d, t), p.device, "pool")
     with _timed("pool_fwd"):
         _lib.check(lib.toad_gated_pool_fwd_f32(_p(p), pb_ptr, ldp, _p(h), _p(wc), _p(bc), _p(a_raw), _p(m), _p(stats),
                                                _p(ws), ws.numel(), n, l, d, t, float(drop_p), int(seed_a), int(seed_b),
@@ -181,8 +234,9 @@ def gated_pool_fwd(p: torch.Tensor, d: int, h: Optional[torch.Tensor], wc, bc, d
 
 def gated_pool_bwd(p, d: int, h, wc, a_raw, stats, m, dm, da_ext=None, dwc=None, dbc=None, beta: float = 0.0,
                    dp: Optional[torch.Tensor] = None, dh: Optional[torch.Tensor] = None,
-                   drop_p: float = 0.0, seed_a: int = 0, seed_b: int = 0):
-    """Returns (dP [N,2D], dH_pool [N,L], dWc [T,D], dbc [T])."""
+                   drop_p: float = 0.0, seed_a: int = 0, seed_b: int = 0, want_dh: bool = True, want_amax: bool = False):
+    """Returns (dP [N,2D], dH_pool [N,L] | None, dWc [T,D], dbc [T]) (+ the abs-max array of dP with want_amax).
+    want_dh=False skips the [N,L] pooling gradient (linear_dgrad(pool=...) recomputes it in its epilogue)."""
     for t_, nm in ((p, "p"), (h, "h"), (wc, "wc"), (a_raw, "a_raw"), (stats, "stats"), (m, "m"), (dm, "dm")):
         _chk(t_, nm)
     _chk(da_ext, "da_ext", allow_none=True)
@@ -193,19 +247,22 @@ def gated_pool_bwd(p, d: int, h, wc, a_raw, stats, m, dm, da_ext=None, dwc=None,
         raise ValueError("gated_pool_bwd: shape mismatch")
     if dp is None:
         dp = torch.empty_like(p)
-    if dh is None:
+    if dh is None and want_dh:
         dh = torch.empty_like(h)
     if dwc is None:
         dwc = torch.empty_like(wc); dbc = torch.empty((t,), dtype=torch.float32, device=p.device); beta = 0.0
-    _chk(dp, "dp"); _chk(dh, "dh"); _chk(dwc, "dwc"); _chk(dbc, "dbc")
+    _chk(dp, "dp"); _chk(dh, "dh", allow_none=True); _chk(dwc, "dwc"); _chk(dbc, "dbc")
     lib = _lib.load()
-    ws = _ws(lib.toad_gated_pool_bwd_ws_bytes(n, l, d, t), p.device)
+    dp_amax = torch.empty((amax_floats(n),), dtype=torch.float32, device=p.device) if want_amax else None
+    ws = _ws(lib.toad_gated_pool_bwd_ws_bytes(n, l, d, t), p.device, "pool")
     with _timed("pool_bwd"):
         _lib.check(lib.toad_gated_pool_bwd_f32(_p(p), p.data_ptr() + 4 * d, ldp, _p(h), _p(wc), _p(a_raw), _p(stats), _p(m),
                                                _p(dm), _p(da_ext), _p(dp), dp.data_ptr() + 4 * d, ldp, _p(dh), _p(dwc),
-                                               _p(dbc), float(beta), _p(ws), ws.numel(), n, l, d, t, float(drop_p),
+                                               _p(dbc), float(beta), _p(dp_amax), _p(ws), ws.numel(), n, l, d, t, float(drop_p),
                                                int(seed_a), int(seed_b), _stream()),
                    "toad_gated_pool_bwd_f32")
+    if want_amax:
+        return dp, dh, dwc, dbc, dp_amax
     return dp, dh, dwc, dbc
 
 
@@ -231,8 +288,9 @@ def heads_fwd(m, sex, wcls, bcls, wsite, bsite):
     return mcat, logits, y_prob, y_hat, site_logits, site_prob, site_hat
 
 
-def heads_bwd(mcat, dlogits, dsite, wcls, wsite, dmcat_ext=None, grads=None, beta: float = 0.0):
-    """Returns (dWcls, dbcls, dWsite, dbsite, dM [2,L]). grads = optional tuple of 4 destination tensors."""
+def heads_bwd(mcat, dlogits, dsite, wcls, wsite, dmcat_ext=None, grads=None, beta: float = 0.0, want_dsex: bool = False):
+    """Returns (dWcls, dbcls, dWsite, dbsite, dM [2,L]) (+ dsex [1] with want_dsex: the gradient of the `sex` scalar
+    appended to both pooled rows, models/model_toad.py:99). grads = optional tuple of 4 destination tensors."""
     for t_, nm in ((mcat, "mcat"), (dlogits, "dlogits"), (dsite, "dsite"), (wcls, "wcls"), (wsite, "wsite")):
         _chk(t_, nm)
     _chk(dmcat_ext, "dmcat_ext", allow_none=True)
@@ -249,9 +307,12 @@ def heads_bwd(mcat, dlogits, dsite, wcls, wsite, dmcat_ext=None, grads=None, bet
     for t_, nm in ((dwcls, "dwcls"), (dbcls, "dbcls"), (dwsite, "dwsite"), (dbsite, "dbsite")):
         _chk(t_, nm)
     dm = torch.empty((2, l), dtype=torch.float32, device=dev)
+    dsex = torch.empty((1,), dtype=torch.float32, device=dev) if want_dsex else None
     _lib.check(_lib.load().toad_heads_bwd_f32(_p(mcat), _p(dlogits), _p(dsite), _p(wcls), _p(wsite), _p(dmcat_ext),
-                                              _p(dwcls), _p(dbcls), _p(dwsite), _p(dbsite), _p(dm), float(beta), l, c,
+                                              _p(dwcls), _p(dbcls), _p(dwsite), _p(dbsite), _p(dm), _p(dsex), float(beta), l, c,
                                               _stream()), "toad_heads_bwd_f32")
+    if want_dsex:
+        return dwcls, dbcls, dwsite, dbsite, dm, dsex
     return dwcls, dbcls, dwsite, dbsite, dm
 
 
@@ -281,26 +342,31 @@ def _ptr_array(tensors):
     return arr
 
 
+def _step_dims(w, bag):
+    c = w["wcls"].shape[0]
+    d = w["wc"].shape[1]
+    if bag.shape[1] != 1024 or w["w1"].shape != (512, 1024) or w["wab"].shape != (2 * d, 512):
+        raise ValueError("whole-slide calls need the TOAD trunk shapes (1024 -> 512 -> 2 x 384|256)")
+    return bag.shape[0], c, d
+
+
 def mil_step(w, grads, beta: float, bag, sex, label, site, w_cls: float = 0.75, w_site: float = 0.25,
-             drop_p: float = 0.0, seed: int = 0, want_logits: bool = False):
+             drop_p: float = 0.0, seed: int = 0, want_logits: bool = False, x_amax: Optional[torch.Tensor] = None):
     """forward + weighted CE + backward for one slide in ONE library call. ``w`` / ``grads`` map the STEP_SLOTS
     to tensors (grads = beta*grads + gradient). Returns (loss[3], logits [1,C] | None, site_logits [1,2] | None)."""
     import ctypes
     _chk(bag, "bag"); _chk(sex, "sex"); _chk(label, "label", dtype=torch.int64); _chk(site, "site", dtype=torch.int64)
+    _chk(x_amax, "x_amax", allow_none=True)
     ws_t = [w[k] for k in STEP_SLOTS]
     gs_t = [grads[k] for k in STEP_SLOTS]
     for k, t in zip(STEP_SLOTS, ws_t):
         _chk(t, k)
     for k, t in zip(STEP_SLOTS, gs_t):
         _chk(t, "grad " + k)
-    n = bag.shape[0]
-    c = w["wcls"].shape[0]
-    d = w["wc"].shape[1]
-    if bag.shape[1] != 1024 or w["w1"].shape != (512, 1024) or w["wab"].shape != (2 * d, 512):
-        raise ValueError("mil_step: shapes must be TOAD 'big' (1024 -> 512 -> 2x384|256)")
+    n, c, d = _step_dims(w, bag)
     lib = _lib.load()
     dev = bag.device
-    ws = _ws(lib.toad_mil_step_ws_bytes(n, c, d), dev)
+    ws = _ws(lib.toad_mil_step_ws_bytes(n, c, d), dev, "step")
     loss = torch.empty((3,), dtype=torch.float32, device=dev)
     logits = torch.empty((1, c), dtype=torch.float32, device=dev) if want_logits else None
     slog = torch.empty((1, 2), dtype=torch.float32, device=dev) if want_logits else None
@@ -312,13 +378,87 @@ def mil_step(w, grads, beta: float, bag, sex, label, site, w_cls: float = 0.75, 
             e.record()                     # materialises the underlying hipEvent_t
         events = (ctypes.c_void_p * 18)(*[e.cuda_event for e in ev_objs])
     _lib.check(lib.toad_mil_step_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag), _p(sex), _p(label), _p(site),
-                                     float(w_cls), float(w_site), n, c, d, float(drop_p), int(seed), _p(loss), _p(logits),
+                                     float(w_cls), float(w_site), n, c, d, float(drop_p), int(seed), _p(x_amax), _p(loss), _p(logits),
                                      _p(slog), _p(ws), ws.numel(), events, _stream()), "toad_mil_step_f32")
     if ev_objs is not None:
         _TIMING.setdefault("pool_fwd", []).append((ev_objs[0], ev_objs[1]))
         for i, name in enumerate(_GEMM_EVENT_NAMES):
             _TIMING.setdefault(name, []).append((ev_objs[2 + 2 * i], ev_objs[3 + 2 * i]))
     return loss, logits, slog
+
+
+# ---- model(data, sex) and loss.backward() as one C call each (toad_mil_fwd_f32 / toad_mil_bwd_f32) ---------------------
+ARENA_SLOTS = ("h1", "h", "p", "a_raw", "stats", "m", "mcat", "logits", "y_prob", "y_hat", "site_logits", "site_prob", "site_hat",
+               "x_amax", "h1_amax", "h_amax")
+
+
+class MilArena:
+    """The forward arena of one slide: saved activations + outputs, as typed views of ONE allocation."""
+
+    def __init__(self, n: int, c: int, d: int, device):
+        import ctypes
+        lib = _lib.load()
+        self.n, self.c, self.d = n, c, d
+        self.buf = torch.empty(int(lib.toad_mil_arena_bytes(n, c, d)), dtype=torch.uint8, device=device)
+        align = int(lib.toad_mil_buffer_align(n))
+        self.base = (-self.buf.data_ptr()) % align
+        offs = (ctypes.c_int64 * len(ARENA_SLOTS))()
+        _lib.check(lib.toad_mil_arena_layout(n, c, d, offs), "toad_mil_arena_layout")
+        self.off = {k: self.base + int(o) for k, o in zip(ARENA_SLOTS, offs)}
+
+    def view(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
+        nbytes = int(torch.empty((), dtype=dtype).element_size())
+        for s_ in shape:
+            nbytes *= int(s_)
+        o = self.off[name]
+        return self.buf[o:o + nbytes].view(dtype).view(*shape)
+
+
+def mil_fwd(w, bag, sex, drop_p: float = 0.0, seed: int = 0, attention_only: bool = False,
+            x_amax: Optional[torch.Tensor] = None) -> MilArena:
+    """models/model_toad.py:90-116 for one bag in ONE library call; returns the arena (outputs + what backward needs)."""
+    _chk(bag, "bag"); _chk(sex, "sex", allow_none=attention_only); _chk(x_amax, "x_amax", allow_none=True)
+    ws_t = [w[k] for k in STEP_SLOTS]
+    for k, t in zip(STEP_SLOTS, ws_t):
+        _chk(t, k)
+    n, c, d = _step_dims(w, bag)
+    lib = _lib.load()
+    arena = MilArena(n, c, d, bag.device)
+    scratch = _ws(lib.toad_mil_scratch_bytes(n, c, d), bag.device, "mil")
+    with _timed("mil_fwd"):
+        _lib.check(lib.toad_mil_fwd_f32(_ptr_array(ws_t), _p(bag), _p(sex), n, c, d, float(drop_p), int(seed), _p(x_amax),
+                                        1 if attention_only else 0, _p(arena.buf), arena.buf.numel(), _p(scratch), scratch.numel(),
+                                        _stream()), "toad_mil_fwd_f32")
+    return arena
+
+
+def mil_bwd(w, grads, beta: float, bag, arena: MilArena, dlogits, dsite, da_ext=None, dmcat_ext=None, drop_p: float = 0.0,
+            seed: int = 0, need_dx: bool = False, need_dsex: bool = False):
+    """Backward of mil_fwd in ONE library call: grads[slot] = beta*grads[slot] + gradient. Returns (dX | None, dsex | None)."""
+    _chk(bag, "bag"); _chk(dlogits, "dlogits"); _chk(dsite, "dsite")
+    _chk(da_ext, "da_ext", allow_none=True); _chk(dmcat_ext, "dmcat_ext", allow_none=True)
+    ws_t = [w[k] for k in STEP_SLOTS]
+    gs_t = [grads[k] for k in STEP_SLOTS]
+    for k, t in zip(STEP_SLOTS, gs_t):
+        _chk(t, "grad " + k)
+    n, c, d = arena.n, arena.c, arena.d
+    if dlogits.numel() != c or dsite.numel() != 2 or bag.shape[0] != n:
+        raise ValueError("mil_bwd: shape mismatch")
+    if da_ext is not None and tuple(da_ext.shape) != (n, 2):
+        raise ValueError("mil_bwd: da_ext must be [N,2]")
+    if dmcat_ext is not None and tuple(dmcat_ext.shape) != (2, 513):
+        raise ValueError("mil_bwd: dmcat_ext must be [2,513]")
+    lib = _lib.load()
+    dev = bag.device
+    dx = torch.empty_like(bag) if need_dx else None
+    dsex = torch.empty((1,), dtype=torch.float32, device=dev) if need_dsex else None
+    scratch = _ws(lib.toad_mil_scratch_bytes(n, c, d), dev, "mil")
+    buf = arena.buf
+    with _timed("mil_bwd"):
+        _lib.check(lib.toad_mil_bwd_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag), n, c, d, float(drop_p), int(seed),
+                                        _p(buf), buf.numel(), _p(dlogits), _p(dsite), _p(da_ext), _p(dmcat_ext), _p(dx), _p(dsex),
+                                        _p(scratch), scratch.numel(), _stream()), "toad_mil_bwd_f32")
+    return dx, dsex
 
 
 # ---- feature-extractor pieces (conv.hip) --------------------------------------------------------------------------

@@ -1,8 +1,9 @@
-"""Optimiser for the flat parameter buffer: one HIP launch per step (toad_adam_step_f32).
+"""Optimisers for the flat parameter buffer: one HIP launch per step.
 
-Same update rule and defaults as the reference's ``get_optim`` Adam branch (utils/utils.py:63-70:
-``optim.Adam(params, lr=args.lr, weight_decay=args.reg)``); the reference's SGD branch and any other
-torch optimiser keep working on ``model.parameters()`` unchanged.
+``FlatAdam`` / ``FlatSGD`` apply the update rules and defaults of the reference's ``get_optim`` (utils/utils.py:63-70:
+``optim.Adam(params, lr=args.lr, weight_decay=args.reg)`` and ``optim.SGD(params, lr=args.lr, momentum=0.9,
+weight_decay=args.reg)``) to all 1.19 M parameters at once; any torch optimiser keeps working on ``model.parameters()``
+unchanged (the drop-in path).
 """
 from __future__ import annotations
 
@@ -35,3 +36,43 @@ class FlatAdam:
     def state_dict(self):
         return {"m": self.m, "v": self.v, "t": self.t, "lr": self.lr, "betas": self.betas, "eps": self.eps,
                 "weight_decay": self.weight_decay}
+
+    def load_state_dict(self, sd) -> None:
+        """Restore the moments and the step count (checkpoint resume); hyper-parameters follow the checkpoint."""
+        if sd["m"].numel() != self.p.numel() or sd["v"].numel() != self.p.numel():
+            raise ValueError("FlatAdam.load_state_dict: moment buffers do not match the flat parameter buffer")
+        self.m.copy_(sd["m"].to(self.m.device).reshape(-1))
+        self.v.copy_(sd["v"].to(self.v.device).reshape(-1))
+        self.t = int(sd["t"])
+        self.lr, self.betas, self.eps = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])
+        self.weight_decay = float(sd["weight_decay"])
+
+
+class FlatSGD:
+    """torch.optim.SGD(lr, momentum, weight_decay) over the flat buffer (toad_sgd_step_f32): get_optim's SGD branch."""
+
+    def __init__(self, flat_param: torch.Tensor, lr: float = 1e-4, momentum: float = 0.9, weight_decay: float = 1e-5):
+        if flat_param.dim() != 1 or flat_param.numel() % 4 != 0:
+            raise ValueError("FlatSGD needs a 1-D buffer whose length is a multiple of 4")
+        self.p = flat_param
+        self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        self.buf = torch.zeros_like(flat_param) if momentum != 0.0 else None
+        self.t = 0
+
+    def step(self, flat_grad: torch.Tensor) -> None:
+        if not self.p.is_cuda:
+            raise RuntimeError("FlatSGD runs on the HIP device only")
+        self.t += 1
+        lib = _lib.load()
+        _lib.check(lib.toad_sgd_step_f32(self.p.data_ptr(), flat_grad.data_ptr(), None if self.buf is None else self.buf.data_ptr(),
+                                         self.p.numel(), float(self.lr), float(self.momentum), float(self.weight_decay), self.t,
+                                         torch.cuda.current_stream().cuda_stream), "toad_sgd_step_f32")
+
+    def state_dict(self):
+        return {"buf": self.buf, "t": self.t, "lr": self.lr, "momentum": self.momentum, "weight_decay": self.weight_decay}
+
+    def load_state_dict(self, sd) -> None:
+        if self.buf is not None and sd["buf"] is not None:
+            self.buf.copy_(sd["buf"].to(self.buf.device).reshape(-1))
+        self.t = int(sd["t"])
+        self.lr, self.momentum, self.weight_decay = float(sd["lr"]), float(sd["momentum"]), float(sd["weight_decay"])

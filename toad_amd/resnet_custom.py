@@ -25,7 +25,13 @@ from . import _lib
 __all__ = ["Bottleneck_Baseline", "ResNet_Baseline", "resnet50_baseline"]
 
 STEM_K = 192            # 4 x 4 space-to-depth taps x 12 channels (147 real taps + zero slots)
-MAX_TILES_PER_CALL = 512     # 32-bit byte offsets inside the kernels: B*64*64*128*4 < 2^31 (layer2.0 conv2 input)
+MAX_TILES_PER_CALL = 512     # at 256x256 tiles. 32-bit byte offsets inside the kernels: B*(H/4)*(W/4)*128*4 < 2^31 (layer2.0 conv2 input)
+
+
+def max_tiles_per_call(h: int, w: int) -> int:
+    """Tiles per C call for H x W tiles: the kernels' 32-bit offsets bound B * H * W, so the cap scales with the tile area
+    (512 at the reference's 256 x 256; 128 at 512 x 512; more for smaller tiles, bounded by the workspace to 4096)."""
+    return max(1, min(4096, (MAX_TILES_PER_CALL * 256 * 256) // max(h * w, 1)))
 
 
 class Bottleneck_Baseline(nn.Module):
@@ -83,6 +89,7 @@ class ResNet_Baseline(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
         self._folded = None           # (weights, biases, ctypes arrays), built lazily on the device
+        self._folded_sig = None
         self._ws: Optional[torch.Tensor] = None
 
     def _make_layer(self, block, planes, blocks, stride=1):
@@ -103,6 +110,11 @@ class ResNet_Baseline(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         self._folded = None
         return super().load_state_dict(*args, **kwargs)
+
+    def _param_signature(self):
+        """(storage address, in-place version) of every parameter and BN statistic: changes whenever weights are loaded
+        (also as a child of a parent module, which bypasses this class's load_state_dict), moved, or edited in place."""
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     def _apply(self, fn, *args, **kwargs):
         self._folded = None
@@ -129,6 +141,7 @@ class ResNet_Baseline(nn.Module):
         wp = (ctypes.c_void_p * 43)(*[t.data_ptr() for t in ws])
         bp = (ctypes.c_void_p * 43)(*[t.data_ptr() for t in bs])
         self._folded = (ws, bs, wp, bp)
+        self._folded_sig = self._param_signature()
 
     def relocate(self):
         if not torch.cuda.is_available():
@@ -145,15 +158,16 @@ class ResNet_Baseline(nn.Module):
         if self.conv1.weight.device != x.device:
             raise RuntimeError("model and input are on different devices; call model.relocate()")
         lib = _lib.load()
-        if self._folded is None:
+        if self._folded is None or self._folded_sig != self._param_signature():
             self._fold_all()
         _, _, wp, bp = self._folded
         x = x.contiguous()
         B, _, H, W = x.shape
         out = torch.empty(B, 1024, device=x.device, dtype=torch.float32)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        for b0 in range(0, B, MAX_TILES_PER_CALL):
-            nb = min(MAX_TILES_PER_CALL, B - b0)
+        cap = max_tiles_per_call(H, W)
+        for b0 in range(0, B, cap):
+            nb = min(cap, B - b0)
             need = lib.toad_resnet50_trunc_ws_bytes(nb, H, W)
             if need == 0:
                 raise RuntimeError(f"unsupported tile shape {H}x{W}")
