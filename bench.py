@@ -1,24 +1,36 @@
-"""bench.py — headline benchmark of the TOAD gated-attention MIL hot path on MI355X.
+"""bench.py — benchmarks of the TOAD gated-attention MIL hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 3                      # headline (the driver's run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --config 2 | 3 | 4 [--gpus N]                        # BASELINE.json configs 2-4
+    python bench.py --dropin [--patches N]                               # the reference's own call sequence, timed
 
-A "step" = one optimiser step of slide-sharded data parallel training: every rank runs
-forward + weighted CE + backward over its own synthetic 100,000-patch x 1024-d bag (fp32, already
-resident in HBM), ONE all-reduce of the 4.77 MB flat gradient over RCCL when N > 1, then Adam.
-value = slides/s over the whole job (N slides per step / max-over-ranks step time).  Weak scaling.
+Headline (no --config). A "step" = one optimiser step of slide-sharded data parallel training: every rank runs
+forward + weighted CE + backward over its own synthetic 100,000-patch x 1024-d bag (fp32, already resident in HBM), ONE
+all-reduce of the 4.77 MB flat gradient over RCCL when N > 1, then Adam. value = slides/s over the whole job (N slides per
+step / max-over-ranks step time). Weak scaling. The JSON line also carries
+  roofline       the fused gated-attention pooling forward (the kernel BASELINE.json's metric names): algorithmic bytes
+                 4*[N*(2D+L+T)+T*D+T+T*L] per launch / mean launch time measured with HIP events on the launch stream inside
+                 the timed steps, vs 8 TB/s HBM;
+  roofline_mfma  all eight GEMM calls of a step: 6,029,312*N algorithmic FLOP / their summed event time. The GEMMs carry
+                 every fp32 operand as two fp16 pieces and every product as THREE fp16 MFMA terms (fp32-equivalent accuracy,
+                 csrc/gemm_h2.inc), so the ceiling is the dense fp16 peak / 3 = 833.3 TFLOP/s fp32-equivalent (the issued
+                 fp16 MFMA rate is reported next to it; round 1's six-term bf16 form had 416.7, the exact-fp32 MFMA peak is
+                 157.3);
+  sustained      the same step repeated for >= 2 s right after the timed region (the K = 20 default lasts ~50 ms, shorter than
+                 the clock governor's settling time);
+  dropin         the reference's own call sequence on the same bag: model(data, sex), torch CrossEntropyLoss x2,
+                 loss.backward(), torch.optim.Adam(model.parameters()).step(), zero_grad()
+                 (utils/core_utils_mtl_concat.py:206-234), which is what a reference user gets without touching the harness;
+  cpu_baseline   the CPU oracle (structurally the reference's PyTorch-CPU op sequence, pinned to the reference in
+                 oracle/pin_against_reference.py) + torch Adam, timed on this box's host cores at its best thread count.
 
-The JSON line also carries
-  roofline       the fused gated-attention pooling forward (the kernel BASELINE.json's metric names):
-                 algorithmic bytes 4*[N*(2D+L+T)+T*D+T+T*L] per launch / mean launch time measured
-                 with HIP events on the launch stream inside the timed steps, vs 8 TB/s HBM;
-  roofline_mfma  all eight GEMM calls of a step: 6,029,312*N algorithmic FLOP / their summed event time. The
-                 GEMMs compute every fp32 product as six bf16 MFMA terms (fp32-equivalent accuracy), so the
-                 ceiling is the dense bf16 peak / 6 = 416.7 TFLOP/s fp32-equivalent (issued bf16 MFMA rate
-                 is reported next to it; the exact-fp32 MFMA peak, 157.3 TF, is given for reference);
-  cpu_baseline   the CPU oracle (structurally the reference's PyTorch-CPU op sequence, pinned to the
-                 reference in oracle/pin_against_reference.py) timed on this box's host cores.
+--config 2   1 GPU, single 100k-patch bag, fused gated-attention pool FORWARD only; value = algorithmic GB/s; the oracle's
+             gated_pool_fwd timed on the host cores beside it.
+--config 3   1 GPU, full step (fwd + CE + bwd + Adam) on 10,000-patch bags; roofline_mfma + cpu_baseline (>= 10 repetitions).
+--config 4   64 slides x 50,000 patches per step, slide i on rank i mod G (shard_round_robin), one gradient all-reduce and one
+             Adam step per 64 slides: STRONG scaling over G = --gpus; runs at G = 1 too.
 """
 from __future__ import annotations
 
@@ -38,9 +50,9 @@ import torch.distributed as dist
 L0, L, D, T, C = 1024, 512, 384, 2, 18
 GEMM_FLOP_PER_PATCH = 6_029_312            # 2,359,296 fwd + 3,670,016 bwd
 HBM_PEAK = 8.0e12                          # MI355X_MICROARCH.md: 8 TB/s spec
-MFMA_BF16_PEAK = 2.5e15                    # dense bf16 MFMA peak (MI355X_MICROARCH.md; 2:1-sparse figures are never used)
-SPLIT_TERMS = 6                            # bf16 MFMAs per fp32-equivalent product (x = h+m+l: hh+hm+mh+mm+hl+lh)
-MFMA_EQ_PEAK = MFMA_BF16_PEAK / SPLIT_TERMS   # 416.7 TFLOP/s fp32-equivalent ceiling of the split-bf16 GEMMs
+MFMA_F16_PEAK = 2.5e15                     # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md; 2:1-sparse figures are never used)
+SPLIT_TERMS = 3                            # fp16 MFMAs per fp32-equivalent product (x*s = h+m: hh + hm + mh)
+MFMA_EQ_PEAK = MFMA_F16_PEAK / SPLIT_TERMS    # 833.3 TFLOP/s fp32-equivalent ceiling of the two-piece GEMMs
 
 
 def pool_fwd_bytes(n):                     # 5,128 B/patch + constants
@@ -68,10 +80,21 @@ def _physical_cores() -> int:
     return os.cpu_count() or 1
 
 
+def _cpu_name() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def measured_pool_traffic(n: int):
     """HBM bytes per launch of the fused pool forward from the committed rocprofv3 PMC passes
     (profiles/r01_pool_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the
-    gfx950 guide prescribes for 16-B/lane streaming loads). Only valid for the N it was measured at."""
+    gfx950 guide prescribes for 16-B/lane streaming loads). Only valid for the N it was measured at (the kernel is unchanged)."""
     try:
         with open(os.path.join(REPO, "profiles", "r01_pool_traffic.json")) as f:
             t = json.load(f)
@@ -82,24 +105,13 @@ def measured_pool_traffic(n: int):
     return None
 
 
-def cpu_baseline(n_patches: int, budget_s: float = 30.0):
-    """fwd + loss + bwd of the CPU oracle on the host cores; bounded sample.
-    PyTorch-CPU does not scale to every hardware thread of a big host (256 threads on this pool's
-    boxes run ~7x slower than 64), so a few thread counts are probed with one repetition each and
-    the FASTEST is then timed (median of >=3) — the baseline is the best the CPU path can do here."""
-    from oracle import toad_oracle as orc       # checker / reported baseline only
+def _probe_threads(once, budget_s: float, min_reps: int):
+    """PyTorch-CPU does not scale to every hardware thread of a big host (256 threads run ~7x slower than 64 here), and the
+    best count depends on the problem size: probe {4, 8, 16, 32, 64, physical} with one repetition each (after a warm-up),
+    then time the FASTEST (median of >= min_reps) - the baseline is the best this CPU path can do on this box."""
     logical = os.cpu_count() or 1
     phys = min(_physical_cores(), logical)
-    params = orc.xavier_params(C, seed=1)
-    x = torch.randn(n_patches, L0, generator=torch.Generator().manual_seed(1000))
-    sex = torch.tensor([0.0]); label = torch.tensor([0]); site = torch.tensor([0])
-
-    def once():
-        t0 = time.perf_counter()
-        orc.fwd_bwd(params, x, sex, label, site)
-        return time.perf_counter() - t0
-
-    cands = sorted({max(1, phys // 4), max(1, phys // 2), phys}) if phys > 8 else [phys]
+    cands = sorted({t for t in (4, 8, 16, 32, 64, phys) if t <= max(phys, 4)})
     probe = {}
     t_start = time.perf_counter()
     for th in cands:
@@ -111,24 +123,149 @@ def cpu_baseline(n_patches: int, budget_s: float = 30.0):
     best = min(probe, key=probe.get)
     torch.set_num_threads(best)
     times = [probe[best]]
-    while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 7):
+    while len(times) < min_reps or (time.perf_counter() - t_start < budget_s and len(times) < max(7, min_reps)):
         times.append(once())
     times.sort()
-    med = times[len(times) // 2]
-    cpu_name = "unknown"
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    cpu_name = line.split(":", 1)[1].strip(); break
-    except OSError:
-        pass
+    return times[len(times) // 2], best, probe, len(times), phys, logical
+
+
+def cpu_baseline_step(n_patches: int, budget_s: float = 30.0, min_reps: int = 3):
+    """fwd + weighted CE + bwd of the CPU oracle + torch.optim.Adam step on the host cores; bounded sample."""
+    from oracle import toad_oracle as orc       # checker / reported baseline only
+    params = {k: torch.nn.Parameter(v.clone()) for k, v in orc.xavier_params(C, seed=1).items()}
+    opt = torch.optim.Adam(params.values(), lr=1e-4, weight_decay=1e-5)          # get_optim defaults (main_mtl_concat.py:93-96)
+    x = torch.randn(n_patches, L0, generator=torch.Generator().manual_seed(1000))
+    sex = torch.tensor([0.0]); label = torch.tensor([0]); site = torch.tensor([0])
+
+    def once():
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            _, _, g = orc.fwd_bwd({k: v.detach() for k, v in params.items()}, x, sex, label, site)
+        for k, p in params.items():
+            p.grad = g[k]
+        opt.step()
+        opt.zero_grad()
+        return time.perf_counter() - t0
+
+    med, best, probe, reps, phys, logical = _probe_threads(once, budget_s, min_reps)
     return {"value": round(1.0 / med, 4), "unit": "slides/s", "cores": best, "kind": "port",
-            "sample": f"median of {len(times)} x (fwd + weighted CE + bwd) of one {n_patches}-patch x 1024-d bag, "
-                      f"oracle/toad_oracle.py (torch CPU fp32, the reference's op sequence) on {cpu_name}, "
+            "sample": f"median of {reps} x (fwd + weighted CE + bwd + Adam step) of one {n_patches}-patch x 1024-d bag, "
+                      f"oracle/toad_oracle.py (torch CPU fp32, the reference's op sequence) on {_cpu_name()}, "
                       f"{phys} physical / {logical} logical cores; threads probed {{"
                       + ", ".join(f"{k}: {v * 1e3:.0f} ms" for k, v in probe.items()) + "}",
             "ms_per_slide": round(med * 1e3, 2)}
+
+
+def cpu_baseline_pool(n_patches: int, budget_s: float = 20.0):
+    """The oracle's gated_pool_fwd (tanh / sigmoid gate, scores, softmax over the bag, A @ H) on the host cores."""
+    from oracle import toad_oracle as orc       # checker / reported baseline only
+    g = torch.Generator().manual_seed(1000)
+    p = torch.randn(n_patches, 2 * D, generator=g); h = torch.randn(n_patches, L, generator=g).relu()
+    wc = torch.randn(T, D, generator=g) * 0.05; bc = torch.zeros(T)
+
+    def once():
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            orc.gated_pool_fwd(p[:, :D], p[:, D:], h, wc, bc)
+        return time.perf_counter() - t0
+
+    med, best, probe, reps, phys, logical = _probe_threads(once, budget_s, 5)
+    return {"value": round(pool_fwd_bytes(n_patches) / med / 1e9, 2), "unit": "GB/s", "cores": best, "kind": "port",
+            "sample": f"median of {reps} x oracle.gated_pool_fwd on one {n_patches}-patch bag (P [N,768], H [N,512] resident in host memory), "
+                      f"{_cpu_name()}, {phys} physical / {logical} logical cores; threads probed {{"
+                      + ", ".join(f"{k}: {v * 1e3:.1f} ms" for k, v in probe.items()) + "}",
+            "ms_per_launch": round(med * 1e3, 3)}
+
+
+def make_slide(idx: int, n: int, dev):
+    """SURVEY.md 8(d) synthetic inputs: N(0,1) bag seeded by the slide index, generated on the device."""
+    g = torch.Generator(device=dev).manual_seed(1000 + idx)
+    bag = torch.randn(n, L0, device=dev, generator=g)
+    return (bag, torch.tensor([float((idx // 2) % 2)], device=dev), torch.tensor([idx % C], device=dev), torch.tensor([idx % 2], device=dev))
+
+
+def gemm_roofline(timing, n_patches_per_set):
+    gemm_ms = sum(timing[k][1] for k in ("gemm_fwd", "gemm_dgrad", "gemm_wgrad"))
+    sets = timing["gemm_fwd"][0] // 3                                   # 3 forward GEMMs per slide
+    gemm_t = gemm_ms / sets * 1e-3
+    tf = GEMM_FLOP_PER_PATCH * n_patches_per_set / gemm_t
+    return {"bound": "mfma",
+            "kernel": "gemm_nt_h2_big_kernel x5 (+split_planes_h2, nt_fixup_h2) + gemm_tn_h2_big_kernel x3 (+slab_reduce_h2)",
+            "achieved": round(tf / 1e12, 2), "peak": round(MFMA_EQ_PEAK / 1e12, 1),
+            "unit": "TFLOP/s fp32-equivalent (algorithmic 2MNK; every product = 3 fp16 MFMA terms, peak = 2500/3)",
+            "frac": round(tf / MFMA_EQ_PEAK, 4), "traffic": None,
+            "fp16_mfma_tflops_issued": round(tf * SPLIT_TERMS / 1e12, 1),
+            "frac_of_round1_six_term_ceiling_416.7": round(tf / (MFMA_F16_PEAK / 6), 4),
+            "fp32_mfma_peak_for_reference": 157.3,
+            "algorithmic_flops": GEMM_FLOP_PER_PATCH * n_patches_per_set, "us_per_slide": round(gemm_t * 1e6, 1)}
+
+
+def time_dropin(n: int, steps: int, warmup: int, dev, host_reads: bool):
+    """The reference's train_loop body (utils/core_utils_mtl_concat.py:201-234) on the drop-in module, resident bags.
+    host_reads adds what the reference's loop reads back per slide (two loss .item(), Y_hat / site_hat for the loggers)."""
+    from toad_amd import TOAD_fc_mtl_concat
+    torch.manual_seed(1)
+    model = TOAD_fc_mtl_concat(dropout=False, n_classes=C)
+    model.relocate()
+    model.train()
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4, weight_decay=1e-5)   # get_optim, utils/utils.py:63-65
+    loss_fn = torch.nn.CrossEntropyLoss()
+    slides = [make_slide(i, n, dev) for i in range(2)]
+
+    def one(i):
+        data, sex, label, site = slides[i % 2]
+        res = model(data, sex)
+        cls_loss = loss_fn(res["logits"], label)
+        site_loss = loss_fn(res["site_logits"], site)
+        loss = cls_loss * 0.75 + site_loss * 0.25
+        if host_reads:
+            _ = (int(res["Y_hat"]), int(label), int(res["site_hat"]), int(site), cls_loss.item(), site_loss.item())
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+
+    for i in range(warmup):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def run_config2(args, dev):
+    """Pool forward only, one resident 100k-patch bag (BASELINE config 2)."""
+    from toad_amd import ops
+    n = args.patches or 100_000
+    g = torch.Generator(device=dev).manual_seed(1000)
+    p = torch.randn(n, 2 * D, device=dev, generator=g); h = torch.randn(n, L, device=dev, generator=g).relu_()
+    wc = torch.randn(T, D, device=dev, generator=g) * 0.05; bc = torch.zeros(T, device=dev)
+    for _ in range(args.warmup):
+        ops.gated_pool_fwd(p, D, h, wc, bc)
+    torch.cuda.synchronize()
+    ops.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ops.gated_pool_fwd(p, D, h, wc, bc)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    calls, tot_ms = ops.collect_timing()["pool_fwd"]
+    ops.enable_timing(False)
+    t = tot_ms / calls * 1e-3
+    bw = pool_fwd_bytes(n) / t
+    out = {"metric": "fused gated-attention pool forward, algorithmic HBM GB/s (100k-patch x 1024-d bag)", "value": round(bw / 1e9, 1),
+           "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"BASELINE config 2: toad_gated_pool_fwd_f32 (tanh*sigmoid gate, scores, online softmax, weighted sum; "
+                                  f"models/model_toad.py:37-40,92,97-98) on one resident {n}-patch bag: P [N,768], H [N,512] -> A_raw [N,2], M [2,512]"},
+           "roofline": {"bound": "hbm", "kernel": "gated_pool_fwd_kernel<2,3,4,true> + gated_pool_combine_kernel", "achieved": round(bw / 1e9, 1),
+                        "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(bw / HBM_PEAK, 4), "traffic": measured_pool_traffic(n),
+                        "algorithmic_bytes": pool_fwd_bytes(n), "us_per_launch": round(t * 1e6, 2)}}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_pool(n)
+        out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -136,9 +273,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--patches", type=int, default=100_000)
+    ap.add_argument("--patches", type=int, default=0, help="patches per slide (default: 100,000; config 3: 10,000; config 4: 50,000)")
     ap.add_argument("--slides-per-rank", type=int, default=1)
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4], help="BASELINE.json config (0 = the headline step)")
+    ap.add_argument("--dropin", action="store_true", help="time only the reference's call sequence on the drop-in module")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="headline run without the extra drop-in timing")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--single-device", action="store_true",
                     help="plumbing test only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
@@ -161,8 +301,21 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    if args.config == 2:
+        return run_config2(args, dev)
+    if args.dropin:
+        n = args.patches or 100_000
+        ms = time_dropin(n, args.steps, args.warmup, dev, host_reads=False)
+        ms_h = time_dropin(n, args.steps, args.warmup, dev, host_reads=True)
+        print(json.dumps({"metric": f"drop-in train_loop body, {n}-patch bags", "value": round(1e3 / ms, 2), "unit": "slides/s", "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "ms_per_step_with_host_reads": round(ms_h, 4),
+                          "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "model(data, sex) + nn.CrossEntropyLoss x2 + loss.backward() + torch.optim.Adam.step() + zero_grad() "
+                                                 "(utils/core_utils_mtl_concat.py:206-234) on toad_amd.TOAD_fc_mtl_concat, resident bags"}}), flush=True)
+        return
+
     from toad_amd import TOAD_fc_mtl_concat, ops
-    from toad_amd.dp import SlideShardedDP
+    from toad_amd.dp import SlideShardedDP, shard_round_robin
 
     torch.manual_seed(1)                                   # main_mtl_concat.py:89 default seed
     model = TOAD_fc_mtl_concat(dropout=False, n_classes=C)
@@ -170,20 +323,21 @@ def main():
     model.train()
     dp = SlideShardedDP(model, {"lr": 1e-4, "weight_decay": 1e-5})      # get_optim defaults (main_mtl_concat.py:93-96), HIP flat Adam
 
-    n = args.patches
-    spr = args.slides_per_rank
-    nbags = 2                                              # alternate two resident bags per slide slot
-    slides = []
-    for b in range(nbags):
-        per = []
-        for s in range(spr):
-            idx = (rank * spr + s) * nbags + b
-            g = torch.Generator(device=dev).manual_seed(1000 + idx)
-            bag = torch.randn(n, L0, device=dev, generator=g)
-            per.append((bag, torch.tensor([float((idx // 2) % 2)], device=dev),
-                        torch.tensor([idx % C], device=dev), torch.tensor([idx % 2], device=dev)))
-        slides.append(per)
-    global_slides = spr * world
+    if args.config == 4:
+        n = args.patches or 50_000
+        global_slides = 64
+        mine = shard_round_robin(global_slides, rank, world)           # slide i -> rank i mod G
+        slides = [[make_slide(i, n, dev) for i in mine]]               # the same 64 resident slides every step
+        nbags = 1
+        scaling = "strong"
+    else:
+        n = args.patches or (10_000 if args.config == 3 else 100_000)
+        spr = args.slides_per_rank
+        nbags = 2                                                      # alternate two resident bags per slide slot
+        slides = [[make_slide((rank * spr + s) * nbags + b, n, dev) for s in range(spr)] for b in range(nbags)]
+        global_slides = spr * world
+        scaling = "weak"
+    patches_per_rank_step = n * len(slides[0])
 
     def sync():
         if world > 1:
@@ -203,49 +357,73 @@ def main():
     ops.enable_timing(False)
     last_loss = float(losses[-1][0].item()) * global_slides
 
+    # sustained rate: keep stepping for >= 2 s (same barrier + synchronize bracketing)
+    sus_steps, sus_t = 0, 0.0
+    if args.config in (0, 3):
+        chunk = max(args.steps, 10)
+        sync()
+        t1 = time.perf_counter()
+        while True:
+            for i in range(chunk):
+                dp.step(slides[i % nbags], global_slides)
+            sync()
+            sus_steps += chunk
+            sus_t = time.perf_counter() - t1
+            flag = torch.tensor([1.0 if sus_t >= 2.0 else 0.0], device=dev)
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)             # every rank leaves the loop together
+            if flag.item() > 0 or sus_steps >= 5000:
+                break
+
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, sus_t], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, sus_t = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = global_slides * args.steps / elapsed
-        calls, tot_ms = timing["pool_fwd"]
-        pool_t = tot_ms / calls * 1e-3
-        pool_bw = pool_fwd_bytes(n) / pool_t
-        gemm_ms = sum(timing[k][1] for k in ("gemm_fwd", "gemm_dgrad", "gemm_wgrad"))
-        gemm_launch_sets = timing["gemm_fwd"][0] // 3                   # 3 forward GEMMs per slide
-        gemm_t = gemm_ms / gemm_launch_sets * 1e-3
-        gemm_tf = GEMM_FLOP_PER_PATCH * n / gemm_t
+        metric = {0: "slides/sec fwd+bwd, 100k-patch x 1024-d bags", 3: "slides/sec fwd+bwd, 10k-patch x 1024-d bags (BASELINE config 3)",
+                  4: "slides/sec fwd+bwd, 64 slides x 50k patches per step, slide-sharded DP (BASELINE config 4)"}[args.config]
+        if args.config == 0 and n != 100_000:
+            metric = f"slides/sec fwd+bwd, {n}-patch x 1024-d bags"
         out = {
-            "metric": "slides/sec fwd+bwd, 100k-patch x 1024-d bags",
+            "metric": metric,
             "value": round(value, 3), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"TOAD_fc_mtl_concat(big, n_classes=18) fwd + 0.75/0.25 CE + bwd + Adam on "
-                                   f"{spr} x {n}-patch x 1024-d N(0,1) bag per GPU per step, bags resident in HBM",
-                       "arithmetic": "fp32 storage/accumulation; GEMM products as split-bf16 (x=h+m+l, 6 MFMA terms) = fp32-equivalent, "
-                                     "verified vs fp64 (tools/gemm_accuracy.py, tools/grad_errors.py)",
+                                   f"{len(slides[0])} x {n}-patch x 1024-d N(0,1) bag(s) per GPU per step, bags resident in HBM"
+                                   + (f"; 64 slides per optimiser step dealt round robin over {world} rank(s)" if args.config == 4 else ""),
+                       "arithmetic": "fp32 storage/accumulation; GEMM operands as two fp16 pieces (x*s = h+m, power-of-two scales), 3 MFMA terms = "
+                                     "fp32-equivalent, verified vs fp64 (tools/split_emulation.py, tests/test_gpu_h2.py)",
                        "patches_per_slide": n, "slides_per_step": global_slides,
                        "parallelism": f"slide-sharded dp{world}, one {4 * model.flat_parameters().numel() / 1e6:.2f} MB grad all-reduce/step"},
-            "roofline": {"bound": "hbm", "kernel": "gated_pool_fwd_kernel<2,3,4,true> + gated_pool_combine_kernel",
-                         "achieved": round(pool_bw / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(pool_bw / HBM_PEAK, 4), "traffic": measured_pool_traffic(n),
-                         "algorithmic_bytes": pool_fwd_bytes(n), "us_per_launch": round(pool_t * 1e6, 2)},
-            "roofline_mfma": {"bound": "mfma",
-                              "kernel": "gemm_nt_split_big_kernel x5 (+split_planes, nt_fixup) + gemm_tn_split_big_kernel x3 (+slab_reduce)",
-                              "achieved": round(gemm_tf / 1e12, 2), "peak": round(MFMA_EQ_PEAK / 1e12, 1),
-                              "unit": "TFLOP/s fp32-equivalent (algorithmic 2MNK; every product = 6 bf16 MFMA terms, peak = 2500/6)",
-                              "frac": round(gemm_tf / MFMA_EQ_PEAK, 4), "traffic": None,
-                              "bf16_mfma_tflops_issued": round(gemm_tf * SPLIT_TERMS / 1e12, 1),
-                              "fp32_mfma_peak_for_reference": 157.3,
-                              "algorithmic_flops": GEMM_FLOP_PER_PATCH * n, "us_per_slide": round(gemm_t * 1e6, 1)},
-            "op_us_per_slide": {k: round(v[1] / (timing["pool_fwd"][0]) * 1e3, 1) for k, v in timing.items()},
-            "last_loss": round(last_loss, 5),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n)
+        if "pool_fwd" in timing:
+            calls, tot_ms = timing["pool_fwd"]
+            pool_t = tot_ms / calls * 1e-3
+            pool_bw = pool_fwd_bytes(n) / pool_t
+            out["roofline"] = {"bound": "hbm", "kernel": "gated_pool_fwd_kernel<2,3,4,true> + gated_pool_combine_kernel",
+                               "achieved": round(pool_bw / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": round(pool_bw / HBM_PEAK, 4), "traffic": measured_pool_traffic(n),
+                               "algorithmic_bytes": pool_fwd_bytes(n), "us_per_launch": round(pool_t * 1e6, 2)}
+            out["roofline_mfma"] = gemm_roofline(timing, n)
+            out["op_us_per_slide"] = {k: round(v[1] / calls * 1e3, 1) for k, v in timing.items()}
+        if sus_steps:
+            out["sustained"] = {"value": round(global_slides * sus_steps / sus_t, 3), "unit": "slides/s", "steps": sus_steps,
+                                "seconds": round(sus_t, 3), "ms_per_step": round(sus_t / sus_steps * 1e3, 3)}
+        out["last_loss"] = round(last_loss, 5)
+        if world == 1 and args.config in (0, 3) and not args.no_dropin:
+            k = max(args.steps, 10)
+            ms = time_dropin(n, k, 3, dev, host_reads=False)
+            ms_h = time_dropin(n, k, 3, dev, host_reads=True)
+            out["dropin"] = {"ms_per_step": round(ms, 4), "value": round(1e3 / ms, 2), "unit": "slides/s", "steps": k,
+                             "ms_per_step_with_host_reads": round(ms_h, 4), "vs_fused_step": round(ms / ms_per_step, 3),
+                             "what": "model(data, sex) + nn.CrossEntropyLoss x2 + loss.backward() + torch.optim.Adam(model.parameters()).step() + "
+                                     "zero_grad() (utils/core_utils_mtl_concat.py:206-234); host reads = the loop's .item() / int() per slide"}
+        if world == 1 and not args.no_cpu_baseline and args.config in (0, 3):
+            out["cpu_baseline"] = cpu_baseline_step(n, budget_s=30.0 if n >= 50_000 else 15.0, min_reps=3 if n >= 50_000 else 10)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -134,7 +134,8 @@ int toad_gated_pool_fwd_f32(const float *Pa, const float *Pb, int64_t ldp, const
  *   dH[i,:] = sum_t p[i,t]*dM[t,:]      (dH == NULL: not written - toad_linear_dgrad_f32 recomputes it in its epilogue)
  *   dPa = (dS Wc) * b*(1-a^2),  dPb = (dS Wc) * a*b*(1-b)   with a=tanh(Pa), b=sigmoid(Pb)
  *   dWc = beta*dWc + dS^T g,  dbc = beta*dbc + column sums of dS
- * dPa/dPb have row stride ldd floats. dp_amax (or NULL): receives the abs-max array of the [N, ldd] dP rows. */
+ * dPa/dPb have row stride ldd floats. dp_amax (or NULL): receives an abs-max array for the dP rows: per 256-row block an UPPER
+ * BOUND of max |dP| (|dS| . max|Wc| per row - all a consumer needs to pick its power-of-two operand scale), not the exact maximum. */
 size_t toad_gated_pool_bwd_ws_bytes(int64_t N, int L, int D, int T);
 int toad_gated_pool_bwd_f32(const float *Pa, const float *Pb, int64_t ldp, const float *H,
                             const float *Wc, const float *A_raw, const float *stats,

@@ -111,3 +111,21 @@ def assert_grad_close(got, ref, rel, scale, what="", floor=0.0):
     err = float((got.detach().cpu().double() - ref.detach().cpu().double()).abs().max())
     tol = rel * scale + floor
     assert err <= tol, f"{what}: max err {err:.3e} > {tol:.3e} (scale {scale:.3e}, rel {err / max(scale, 1e-300):.2e})"
+
+
+def relu_flips(params, x, h1_dev, h_dev):
+    """Positions where the device's ReLU masks (h1 > 0, h > 0) differ from the masks of the exact (fp64) forward, and a check
+    that every such flip is LEGITIMATE: the exact pre-activation there is within fp32 round-off of zero (two correct fp32
+    implementations can land on either side). Returns the number of flips. models/model_toad.py:59-64."""
+    p = {k: v.double() for k, v in params.items()}
+    z1 = torch.addmm(p["attention_net.0.bias"], x.double(), p["attention_net.0.weight"].t())
+    h1d = h1_dev.detach().cpu()
+    f1 = (h1d > 0) != (z1 > 0)
+    # layer 2 sees the device's own h1 (its flips upstream are already accounted for)
+    z2 = torch.addmm(p["attention_net.2.bias"], h1d.double(), p["attention_net.2.weight"].t())
+    f2 = (h_dev.detach().cpu() > 0) != (z2 > 0)
+    for z, f, nm in ((z1, f1, "h1"), (z2, f2, "h")):
+        if f.any():
+            worst = z[f].abs().max().item()
+            assert worst <= 2e-5 * max(z.abs().max().item(), 1e-30), f"{nm}: mask flip at |pre-activation| = {worst:.3e} is not round-off"
+    return int(f1.sum()) + int(f2.sum())

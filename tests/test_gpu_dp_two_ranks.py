@@ -1,0 +1,112 @@
+"""GPU: the multi-rank path of slide-sharded DP on the REAL kernels. Two processes share cuda:0 (gloo carries the all-reduce:
+RCCL refuses two ranks on one device; the driver's 8-GPU run uses backend "nccl" with the same code path), each runs
+hip_slide_grad (toad_mil_step_f32) on its shard, then SlideShardedDP.step with the flat HIP Adam. Checks:
+  (i)   both ranks end with bitwise identical parameters and reduced gradients;
+  (ii)  the parameters equal a single-process run over the same slides (bitwise for the gradient bucket up to the summation
+        order of the two partial sums: 1e-6 on parameters after the Adam step);
+  (iii) the reduced gradient is the mean of the per-slide ORACLE gradients (the DP parity definition).
+Also exercises length-balanced sharding (shard_by_length) on the GPU.
+What is NOT reproduced, by design: the reference's intra-bag nn.DataParallel (models/model_toad.py:79-81)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import toad_oracle as orc
+from tests.helpers import assert_grad_close, grad_scale
+
+pytestmark = pytest.mark.gpu
+
+LENS = [1500, 300, 777, 2049]
+C = 18
+
+
+def make_slide(i, dev="cpu"):
+    g = torch.Generator().manual_seed(2000 + i)
+    s = (torch.randn(LENS[i], 1024, generator=g), torch.tensor([float((i // 2) % 2)]), torch.tensor([(3 * i) % C]), torch.tensor([i % 2]))
+    return tuple(t.to(dev) for t in s)
+
+
+def build_model(seed):
+    from toad_amd import TOAD_fc_mtl_concat
+    torch.manual_seed(seed)
+    m = TOAD_fc_mtl_concat(n_classes=C)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.05)
+    return m
+
+
+def worker(rank, world, port, ret, balanced):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from toad_amd.dp import SlideShardedDP, shard_by_length, shard_round_robin
+    model = build_model(100 + rank)                     # replicas start DIFFERENT: the construction broadcast must fix that
+    model.relocate()
+    model.train()
+    dp = SlideShardedDP(model, {"lr": 1e-3, "weight_decay": 1e-5})
+    start = model.flat_parameters().clone()
+    mine = shard_by_length(LENS, rank, world) if balanced else shard_round_robin(len(LENS), rank, world)
+    first = None
+    for step in range(2):                               # two optimiser steps: the second runs on parameters the first one produced
+        dp.step([make_slide(i, "cuda") for i in mine], len(LENS))
+        if step == 0:
+            first = dp.flat_grad.clone()
+    ret[rank] = (start.cpu(), first.cpu(), model.flat_parameters().cpu().clone(), mine)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("balanced", [False, True])
+def test_two_ranks_on_the_real_kernels(cuda, balanced):
+    world, port = 2, 29600 + os.getpid() % 1500 + (50 if balanced else 0)
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    mp.spawn(worker, args=(world, port, ret, balanced), nprocs=world, join=True)
+    (s0, g0, p0, m0), (s1, g1, p1, m1) = ret[0], ret[1]
+    assert sorted(m0 + m1) == list(range(len(LENS))) and not set(m0) & set(m1)
+    if balanced:
+        assert abs(sum(LENS[i] for i in m0) - sum(LENS[i] for i in m1)) <= max(LENS)
+    assert torch.equal(s0, s1), "replicas must be identical after the construction broadcast"
+    assert torch.equal(g0, g1) and torch.equal(p0, p1), "every rank holds the same reduced gradient / parameters"
+
+    # (ii) single process, same slides, same start (rank 0's initialisation)
+    from toad_amd.dp import SlideShardedDP
+    model = build_model(100)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.relocate(); model.train()
+    dp = SlideShardedDP(model, {"lr": 1e-3, "weight_decay": 1e-5})
+    assert torch.equal(model.flat_parameters().cpu(), s0)
+    slides = [make_slide(i, "cuda") for i in range(len(LENS))]
+    dp.step(slides, len(LENS))
+    g_single = dp.flat_grad.cpu().clone()
+    dp.step(slides, len(LENS))
+    assert (g_single - g0).abs().max().item() <= 1e-6 * max(g_single.abs().max().item(), 1e-30) + 1e-9
+    assert (model.flat_parameters().cpu() - p0).abs().max().item() <= 1e-6
+
+    # (iii) reduced gradient == mean of the oracle's per-slide gradients (fp64 yardstick for ReLU-boundary flips)
+    offs, _ = model.flat_offsets()
+    from tests.helpers import SLOT2KEY
+    mean32 = {k: torch.zeros_like(v) for k, v in params.items()}
+    mean64 = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in params.items()}
+    p64 = {k: v.double() for k, v in params.items()}
+    for i in range(len(LENS)):
+        s = make_slide(i)
+        _, _, g = orc.fwd_bwd(params, *s)
+        _, _, gd = orc.fwd_bwd(p64, s[0].double(), s[1].double(), s[2], s[3])
+        for k in mean32:
+            mean32[k] += g[k] / len(LENS)
+            mean64[k] += gd[k] / len(LENS)
+    for slot, key in SLOT2KEY.items():
+        o, n = offs[slot]
+        got = g0[o:o + n].view_as(params[key])
+        dev = (mean32[key].double() - mean64[key]).abs().max().item()
+        assert_grad_close(got, mean64[key], 2e-5, grad_scale(mean64, key), what=key, floor=10.0 * dev)

@@ -36,7 +36,8 @@ def test_linear_fwd_is_transpose_sensitive(cuda):
     x = torch.eye(n)
     w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) / 251.0
     y = ops.linear_act_fwd(x.to(cuda), w.to(cuda), None, 0).cpu()
-    assert torch.equal(y, w.t())
+    # (two fp16 pieces carry 22-23 significand bits: 1.0 * w is w to 2^-22, not bit for bit - a swapped index is off by O(1))
+    assert (y - w.t()).abs().max().item() <= 2.0 ** -21
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 512, 512), (65, 768, 512), (1000, 512, 512), (5000, 768, 512)])

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import toad_oracle as orc
-from tests.helpers import SLOT2KEY, assert_grad_close, case_inputs, check_outputs_vs_golden, grad_scale
+from tests.helpers import SLOT2KEY, assert_grad_close, case_inputs, check_outputs_vs_golden, grad_scale, relu_flips
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +34,27 @@ def test_module_matches_reference_golden(cuda, golden, name):
     out = {k: v.detach().cpu() for k, v in res.items()}
     grads = {k: p.grad for k, p in model.named_parameters()}
     assert set(grads) == set(orc.PARAM_KEYS)
-    check_outputs_vs_golden(golden, name, out, loss.item(), grads, atol=1e-4)
+    # Gradients vs the reference are only comparable element-wise when both sides took the same ReLU branches. The closed-form
+    # golden bags put some pre-activations within round-off of zero; where this implementation lands on the other side of zero
+    # than the exact forward (a LEGITIMATE flip: relu_flips asserts |pre-activation| is round-off there), a whole dZ row differs
+    # and the gradient is compared with the fp64 backward on the device's own activations instead (same bound, identical masks).
+    from toad_amd import functional as F_
+    w = {s_: ci["params"][k].to(cuda) for s_, k in SLOT2KEY.items()}
+    n_flips = 0
+    if ci["n"] > 0:
+        outs, sv = F_.mil_forward(w, data, sex)
+        assert torch.equal(outs["logits"], res["logits"].detach())          # the per-op route is bitwise the module's
+        n_flips = relu_flips(ci["params"], ci["x"], sv.h1, sv.h)
+    check_outputs_vs_golden(golden, name, out, loss.item(), grads if n_flips == 0 else None, atol=1e-4)
+    if n_flips:
+        dl, ds = orc.loss_grad(outs["logits"].cpu(), ci["label"], outs["site_logits"].cpu(), ci["site"])
+        sv_cpu = orc.Saved(x=ci["x"], h1=sv.h1.cpu(), h=sv.h.cpu(), p=sv.p.cpu(), a_raw=sv.a_raw.cpu(), m=sv.m.cpu(), mcat=sv.mcat.cpu(), sex=ci["sex"])
+        s64 = orc.Saved(**{k: (v.double() if (v is not None and v.is_floating_point()) else v) for k, v in sv_cpu.__dict__.items()})
+        og = orc.backward({k: v.double() for k, v in ci["params"].items()}, s64, dl.double(), ds.double())
+        o32 = orc.backward(ci["params"], sv_cpu, dl, ds)
+        for k in orc.PARAM_KEYS:
+            noise = (o32[k].double() - og[k]).abs().max().item()
+            assert_grad_close(grads[k], og[k], 2e-5, grad_scale(og, k), what=f"{name}:{k} ({n_flips} legit ReLU flips)", floor=10.0 * noise)
     a_only = model(data, sex, attention_only=True)
     assert a_only.shape == (ci["n"],)
     assert torch.equal(a_only, res["A"][0].detach())

@@ -93,11 +93,15 @@ bool h2_nt_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc);
 size_t h2_planes_bytes(int64_t N, int64_t K);
 size_t h2_binv_bytes(int64_t N);
 size_t h2_slab_bytes();
-int launch_split_h2(const H2Operand *ops, int n, hipStream_t st, const char *what);
-int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax, hipStream_t st, const char *what);
+int launch_split_h2(const H2Operand *ops, int n, float *zero, int zero_n, hipStream_t st, const char *what);   // also zeroes zero[0..zero_n)
+int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax, bool zero, hipStream_t st, const char *what);
 int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C,
                  int64_t ldc, int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
                  const float *mask_src, H2Pool pool, float *slabs, float *y_amax, hipStream_t st, const char *what);
+int launch_pool_bwd(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *A_raw, const float *stats,
+                    const float *M, const float *dM, const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH, float *dWc, float *dbc,
+                    float beta, float *dp_amax, bool zero_amax, void *ws, size_t ws_bytes, int64_t N, int L, int D, int T, float drop_p,
+                    uint64_t seed_a, uint64_t seed_b, hipStream_t st);
 int launch_wgrad(const float *dY, const float *dy_amax, const float *X, const float *x_amax, float *dW, float *db, int64_t M,
                  int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what);
 

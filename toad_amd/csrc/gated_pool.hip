@@ -330,12 +330,15 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
     }
     __syncthreads();
 
-    float mt[T], il[T], ct[T];
+    float mt[T], il[T], ct[T], wcm[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         mt[t] = stats[2 * t];
         il[t] = 1.f / stats[2 * t + 1];
         ct[t] = s_c[t];
+        float mw = 0.f;                                     // max |Wc[t,:]| for the abs-max bound of dP below
+        for (int e = lane; e < D; e += 64) mw = __builtin_fmaxf(mw, __builtin_fabsf(s_wc[t][e]));
+        wcm[t] = h2_wave_max(mw);
     }
     f32x4 dwc[T][DQ];
     float dbc[T];
@@ -399,7 +402,6 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
         // --- P side
         float *dpa = dPa + rr * ldd + c * 4;
         float *dpb = dPb + rr * ldd + c * 4;
-        float pmax = 0.f;                                   // abs-max of the dP values this lane stores in this step
 #pragma unroll
         for (int j = 0; j < DQ; ++j) {
             f32x4 oa, ob;
@@ -430,12 +432,22 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
             if (valid) {
                 st4(dpa + 4 * LPR * j, oa);
                 st4(dpb + 4 * LPR * j, ob);
-                pmax = __builtin_fmaxf(pmax, __builtin_fmaxf(h2_absmax4(oa), h2_absmax4(ob)));
             }
         }
-        if (dp_amax) {                                      // a step's rows lie inside one 256-row block (256 % ROWS_PER_BLOCK_STEP == 0)
-            pmax = h2_wave_max(pmax);
-            if (lane == 0) h2_atomic_amax(dp_amax + (tile * ROWS_PER_BLOCK_STEP) / H2_ROWBLK, pmax);
+        if (dp_amax) {
+            // The abs-max array only has to BOUND |dP| from above (it picks a power-of-two scale with 2 bits of headroom to spare
+            // per 4x of slack), so instead of reducing 24 stored values per lane it uses, per row,
+            //   |dPa|, |dPb| <= |dg| ka kb,  |dg| <= sum_t |dS_t| max_e |Wc[t,e]|     (|a|, b, 1-a^2 <= 1; ka, kb <= 1/(1-p))
+            // which every lane of the row already holds: one cross-row exchange and one atomic per wave step. A step's rows lie
+            // inside one 256-row block (256 % ROWS_PER_BLOCK_STEP == 0).
+            float bound = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) bound = fmaf(__builtin_fabsf(ds[t]), wcm[t], bound);
+            if (dropping) bound *= drop_a.scale * drop_b.scale;
+            bound = valid ? bound : 0.f;
+            if (RPW == 2) bound = __builtin_fmaxf(bound, __shfl_xor(bound, 32));
+            else bound = h2_wave_max(bound);
+            if (lane == 0) h2_atomic_amax(dp_amax + (tile * ROWS_PER_BLOCK_STEP) / H2_ROWBLK, bound);
         }
     }
 
@@ -595,12 +607,10 @@ extern "C" size_t toad_gated_pool_bwd_ws_bytes(int64_t N, int L, int D, int T) {
     return (size_t)pool_grid(N) * (size_t)bwd_partial_floats(D, T) * sizeof(float);
 }
 
-extern "C" int toad_gated_pool_bwd_f32(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc,
-                                        const float *A_raw, const float *stats, const float *M, const float *dM,
-                                        const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH,
-                                        float *dWc, float *dbc, float beta, float *dp_amax, void *ws, size_t ws_bytes,
-                                        int64_t N, int L, int D, int T, float drop_p, uint64_t seed_a, uint64_t seed_b,
-                                        void *stream) {
+int toad::launch_pool_bwd(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *A_raw,
+                          const float *stats, const float *M, const float *dM, const float *dA_ext, float *dPa, float *dPb, int64_t ldd,
+                          float *dH, float *dWc, float *dbc, float beta, float *dp_amax, bool zero_amax, void *ws, size_t ws_bytes, int64_t N,
+                          int L, int D, int T, float drop_p, uint64_t seed_a, uint64_t seed_b, hipStream_t st) {
     const char *what = "toad_gated_pool_bwd_f32";
     if (!(drop_p >= 0.f && drop_p < 1.f)) { set_error("%s: drop_p must be in [0,1)", what); return TOAD_EINVAL; }
     const DropArgs da = make_drop(drop_p, seed_a), db = make_drop(drop_p, seed_b);
@@ -610,10 +620,9 @@ extern "C" int toad_gated_pool_bwd_f32(const float *Pa, const float *Pb, int64_t
     if (ldp < D || ldp % 4 != 0 || ldd < D || ldd % 4 != 0) { set_error("%s: bad row stride", what); return TOAD_ESHAPE; }
     if (!aligned16(Pa) || !aligned16(Pb) || !aligned16(H) || !aligned16(dPa) || !aligned16(dPb) || (dH && !aligned16(dH)) || !aligned16(ws)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
     if (ws_bytes < toad_gated_pool_bwd_ws_bytes(N, L, D, T)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
-    hipStream_t st = (hipStream_t)stream;
     const int grid = pool_grid(N);
     static_assert(H2_ROWBLK % ROWS_PER_BLOCK_STEP == 0, "a block step must not straddle two abs-max blocks");
-    if (dp_amax) (void)hipMemsetAsync(dp_amax, 0, (size_t)((N + H2_ROWBLK - 1) / H2_ROWBLK) * sizeof(float), st);
+    if (dp_amax && zero_amax) (void)hipMemsetAsync(dp_amax, 0, (size_t)((N + H2_ROWBLK - 1) / H2_ROWBLK) * sizeof(float), st);
     launch_bwd(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, (float *)ws, dp_amax, (int)N, da, db);
     int rc = check_launch(what);
     if (rc) return rc;
@@ -621,4 +630,14 @@ extern "C" int toad_gated_pool_bwd_f32(const float *Pa, const float *Pb, int64_t
     hipLaunchKernelGGL(bwd_partial_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, st, (const float *)ws, grid,
                        bwd_partial_floats(D, T), T * D, T, dWc, dbc, beta);
     return check_launch(what);
+}
+
+extern "C" int toad_gated_pool_bwd_f32(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc,
+                                        const float *A_raw, const float *stats, const float *M, const float *dM,
+                                        const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH,
+                                        float *dWc, float *dbc, float beta, float *dp_amax, void *ws, size_t ws_bytes,
+                                        int64_t N, int L, int D, int T, float drop_p, uint64_t seed_a, uint64_t seed_b,
+                                        void *stream) {
+    return launch_pool_bwd(Pa, Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, dWc, dbc, beta, dp_amax, true, ws, ws_bytes,
+                           N, L, D, T, drop_p, seed_a, seed_b, (hipStream_t)stream);
 }

@@ -121,9 +121,11 @@ size_t h2_slab_bytes() { return (size_t)PB_GRID * PB * PB * sizeof(float); }
 size_t h2_binv_bytes(int64_t N) { return (size_t)((N + PB - 1) / PB) * PB * sizeof(float); }
 
 // split up to 6 weight operands into planes + inverse row scales with ONE launch
-int launch_split_h2(const H2Operand *ops, int n, hipStream_t st, const char *what) {
+int launch_split_h2(const H2Operand *ops, int n, float *zero, int zero_n, hipStream_t st, const char *what) {
     H2SplitBatch b;
     b.n = n;
+    b.zero = zero;
+    b.zero_n = zero ? zero_n : 0;
     int waves = 0;
     for (int i = 0; i < 6; ++i) {
         if (i < n) {
@@ -138,9 +140,9 @@ int launch_split_h2(const H2Operand *ops, int n, hipStream_t st, const char *wha
     hipLaunchKernelGGL(split_planes_h2_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, b);
     return check_launch(what);
 }
-int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax, hipStream_t st, const char *what) {
+int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax, bool zero, hipStream_t st, const char *what) {
     const int nblk = (int)h2_nblk(M);
-    (void)hipMemsetAsync(amax, 0, (size_t)nblk * sizeof(float), st);
+    if (zero) (void)hipMemsetAsync(amax, 0, (size_t)nblk * sizeof(float), st);
     hipLaunchKernelGGL(absmax_rows256_kernel, dim3(4, nblk), dim3(256), 0, st, X, ld, (int)M, (int)K, amax);
     return check_launch(what);
 }
@@ -161,7 +163,7 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
     int max_rem = 0;                                   // fix-up grid: only as many tile rows as some XCD has remainder tiles
     for (int x = 0; x < kNumXCD; ++x) { const int r = nt_plan(x, tiles_m, tiles_n, (int)(K / BK)).rem; if (r > max_rem) max_rem = r; }
     if (max_rem > 0) {
-        hipLaunchKernelGGL(nt_fixup_h2_kernel, dim3(64, max_rem, kNumXCD), dim3(256), 0, st, (const float *)slabs, a_amax, binv, C, ldc,
+        hipLaunchKernelGGL(nt_fixup_h2_kernel, dim3(16, max_rem, kNumXCD), dim3(256), 0, st, (const float *)slabs, a_amax, binv, C, ldc,
                            (int)M, (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, y_amax, tiles_m, tiles_n);
         rc = check_launch(what);
     }
@@ -191,11 +193,11 @@ static int launch_nt_auto(const float *A, int64_t lda, const float *a_amax, cons
         w += h2_binv_bytes(N);
         float *amax_ws = reinterpret_cast<float *>(w);
         if (!a_amax) {
-            if (int rc = launch_absmax(A, lda, M, K, amax_ws, st, what)) return rc;
+            if (int rc = launch_absmax(A, lda, M, K, amax_ws, true, st, what)) return rc;
             a_amax = amax_ws;
         }
         const H2Operand op{B, ldb, 1, N, K, planes, binv};
-        if (int rc = launch_split_h2(&op, 1, st, what)) return rc;
+        if (int rc = launch_split_h2(&op, 1, nullptr, 0, st, what)) return rc;
         return launch_nt_h2(A, lda, a_amax, planes, binv, C, ldc, M, N, K, bias, es, addend, mask_src, pool, slabs, y_amax, st, what);
     }
     if (pool.T > 0) { set_error("%s: the recomputed pooling addend needs the h2 kernel (K %% 32 == 0, M*K*4 < 2^32, workspace)", what); return TOAD_ESHAPE; }
@@ -336,7 +338,7 @@ extern "C" int toad_absmax_rows256_f32(const float *X, int64_t M, int64_t K, flo
     if (!X || !amax || M <= 0 || K <= 0 || K % 4 != 0) { set_error("%s: bad argument", what); return TOAD_EINVAL; }
     if (M > INT32_MAX - 256) { set_error("%s: M too large", what); return TOAD_ESHAPE; }
     if (!aligned16(X)) { set_error("%s: X must be 16-byte aligned", what); return TOAD_EALIGN; }
-    return launch_absmax(X, K, M, K, amax, (hipStream_t)stream, what);
+    return launch_absmax(X, K, M, K, amax, true, (hipStream_t)stream, what);
 }
 
 static int check_ws(void *ws, size_t ws_bytes, int64_t M, int64_t N, int64_t K, const char *what) {
@@ -467,8 +469,8 @@ int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, co
             h2 = true;
             scales = slab + (size_t)nsplit * (size_t)(N * K + N);
             float *amax_ws = scales + 16;
-            if (!dy_amax) { if ((rc = launch_absmax(dY, N, M, N, amax_ws, st, what))) return rc; dy_amax = amax_ws; }
-            if (!x_amax) { float *a2 = amax_ws + h2_nblk(M) + 16; if ((rc = launch_absmax(X, K, M, K, a2, st, what))) return rc; x_amax = a2; }
+            if (!dy_amax) { if ((rc = launch_absmax(dY, N, M, N, amax_ws, true, st, what))) return rc; dy_amax = amax_ws; }
+            if (!x_amax) { float *a2 = amax_ws + h2_nblk(M) + 16; if ((rc = launch_absmax(X, K, M, K, a2, true, st, what))) return rc; x_amax = a2; }
             hipLaunchKernelGGL(gemm_tn_h2_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, dy_amax, X, K, x_amax, slab, cs, scales,
                                (int)M, (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
         } else if (tn_split)

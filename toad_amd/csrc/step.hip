@@ -45,8 +45,8 @@ static size_t arena_layout(const MilShape &s, int64_t *o) {
     o[A_SLOG] = c.take(8, 256);
     o[A_SPROB] = c.take(8, 256);
     o[A_SHAT] = c.take(8, 256);
-    o[A_AMAX_X] = c.take(nb, 256);
-    o[A_AMAX_H1] = c.take(nb, 256);       // h1 / h arrays are adjacent: one memset zeroes both before the GEMM epilogues fill them
+    o[A_AMAX_X] = c.take(nb, 256);        // the three arrays are adjacent: the weight-split launch zeroes them in one go
+    o[A_AMAX_H1] = c.take(nb, 4);
     o[A_AMAX_H] = c.take(nb, 4);
     return up(c.off, 256);
 }
@@ -149,13 +149,14 @@ static int forward_body(const MilShape &s, const Params &p, const float *X, cons
     const EpiScalars relu1{1, 1.f, make_drop(drop_p, ds.s1)}, relu2{1, 1.f, make_drop(drop_p, ds.s2)}, lin{0, 1.f, make_drop(0.f, 0)};
     const H2Pool nopool{nullptr, nullptr, nullptr, 0};
     if (h2) {
-        if (x_amax) (void)hipMemcpyAsync(f.amax_x, x_amax, toad_amax_floats(N) * sizeof(float), hipMemcpyDeviceToDevice, st);
-        else TOAD_TRY(launch_absmax(X, kL0, N, kL0, f.amax_x, st, what));
-        (void)hipMemsetAsync(f.amax_h1, 0, (size_t)((char *)f.amax_h - (char *)f.amax_h1) + toad_amax_floats(N) * sizeof(float), st);
         const H2Operand ops[3] = {{p.w1, kL0, 1, kL, kL0, w.planes[W_1], w.binv[W_1]},
                                   {p.w2, kL, 1, kL, kL, w.planes[W_2], w.binv[W_2]},
                                   {p.wab, kL, 1, D2, kL, w.planes[W_AB], w.binv[W_AB]}};
-        TOAD_TRY(launch_split_h2(ops, 3, st, what));
+        // one launch splits the three forward weight operands AND zeroes the three adjacent abs-max arrays (x, h1, h): no memsets
+        const int nz = (int)(((char *)f.amax_h - (char *)f.amax_x) / sizeof(float) + toad_amax_floats(N));
+        TOAD_TRY(launch_split_h2(ops, 3, f.amax_x, nz, st, what));
+        if (x_amax) (void)hipMemcpyAsync(f.amax_x, x_amax, toad_amax_floats(N) * sizeof(float), hipMemcpyDeviceToDevice, st);
+        else TOAD_TRY(launch_absmax(X, kL0, N, kL0, f.amax_x, false, st, what));
         ev(2); TOAD_TRY(launch_nt_h2(X, kL0, f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nopool, w.slabs, f.amax_h1, st, what)); ev(3);
         ev(4); TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nopool, w.slabs, f.amax_h, st, what)); ev(5);
         ev(6); TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nopool, w.slabs, nullptr, st, what)); ev(7);
@@ -183,14 +184,15 @@ static int backward_body(const MilShape &s, const Params &p, float *const *grads
     const EpiScalars msk{0, ds.mscale, make_drop(0.f, 0)}, plain{0, 1.f, make_drop(0.f, 0)};
     const H2Pool nopool{nullptr, nullptr, nullptr, 0};
     if (h2) {
-        (void)hipMemsetAsync(w.amax_dP, 0, (size_t)((char *)w.amax_dZ1 - (char *)w.amax_dP) + toad_amax_floats(N) * sizeof(float), st);
-        // dgrad operands B[n,k] = W[k,n], read transposed in place: no transpose launches
+        // dgrad operands B[n,k] = W[k,n], read transposed in place: no transpose launches; the same launch zeroes the three
+        // adjacent abs-max arrays of this pass (dP, dZ2, dZ1)
         const H2Operand ops[3] = {{p.wab, 1, kL, kL, D2, w.planes[W_ABT], w.binv[W_ABT]},
                                   {p.w2, 1, kL, kL, kL, w.planes[W_2T], w.binv[W_2T]},
                                   {p.w1, 1, kL0, kL0, kL, w.planes[W_1T], w.binv[W_1T]}};
-        TOAD_TRY(launch_split_h2(ops, dX ? 3 : 2, st, what));
-        TOAD_TRY(toad_gated_pool_bwd_f32(f.P, f.P + s.D, D2, f.H, p.wc, f.A_raw, f.stats, f.M, dM, dA_ext, w.dP, w.dP + s.D, D2, nullptr,
-                                         grads[6], grads[7], beta, w.amax_dP, w.poolb_ws, w.poolb_ws_bytes, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st));
+        const int nz = (int)(((char *)w.amax_dZ1 - (char *)w.amax_dP) / sizeof(float) + toad_amax_floats(N));
+        TOAD_TRY(launch_split_h2(ops, dX ? 3 : 2, w.amax_dP, nz, st, what));
+        TOAD_TRY(launch_pool_bwd(f.P, f.P + s.D, D2, f.H, p.wc, f.A_raw, f.stats, f.M, dM, dA_ext, w.dP, w.dP + s.D, D2, nullptr,
+                                 grads[6], grads[7], beta, w.amax_dP, false, w.poolb_ws, w.poolb_ws_bytes, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st));
         ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what)); ev(9);
         // dZ2 = (dP Wab + dH_pool) * (H > 0): the pooling gradient dH_pool is recomputed in the epilogue from A_raw, stats, dM
         ev(10); TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, nullptr, f.H,
