@@ -121,8 +121,8 @@ def relu_flips(params, x, h1_dev, h_dev):
     z1 = torch.addmm(p["attention_net.0.bias"], x.double(), p["attention_net.0.weight"].t())
     h1d = h1_dev.detach().cpu()
     f1 = (h1d > 0) != (z1 > 0)
-    # layer 2 sees the device's own h1 (its flips upstream are already accounted for)
-    z2 = torch.addmm(p["attention_net.2.bias"], h1d.double(), p["attention_net.2.weight"].t())
+    # layer 2 of the EXACT chain (the reference's fp64 run is the comparison target: its h comes from its own exact h1)
+    z2 = torch.addmm(p["attention_net.2.bias"], torch.relu(z1), p["attention_net.2.weight"].t())
     f2 = (h_dev.detach().cpu() > 0) != (z2 > 0)
     for z, f, nm in ((z1, f1, "h1"), (z2, f2, "h")):
         if f.any():

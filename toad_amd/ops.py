@@ -18,11 +18,31 @@ ACT_NONE, ACT_RELU = 0, 1
 # Events are recorded on the stream the kernels are launched on (the current torch stream), so the
 # elapsed time is device time of exactly the launches made by that C-ABI call.
 _TIMING = None
+_TIMING_LEVEL = 2          # 1: only the fused pool forward is bracketed (2 events per slide); 2: pool + the eight GEMM calls (18)
+_EVENT_POOL = []           # events created AND recorded once ahead of time, so a timed region pays no event creation
 
 
-def enable_timing(on: bool = True) -> None:
-    global _TIMING
+def enable_timing(on: bool = True, level: int = 2, prealloc: int = 0) -> None:
+    """Switch per-op HIP-event timing on / off. Event packets are not free (18 per slide cost ~0.1 ms of stream time), so a
+    throughput measurement uses level 1 (two events around the dominant kernel) and a separate instrumented loop level 2.
+    `prealloc` events are created and materialised now, outside any timed region."""
+    global _TIMING, _TIMING_LEVEL
     _TIMING = {} if on else None
+    _TIMING_LEVEL = level
+    if on and prealloc > 0 and torch.cuda.is_available():
+        for _ in range(prealloc):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()                     # materialises the underlying hipEvent_t
+            _EVENT_POOL.append(e)
+        torch.cuda.synchronize()
+
+
+def _take_event():
+    if _EVENT_POOL:
+        return _EVENT_POOL.pop()
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
 
 
 def collect_timing():
@@ -373,17 +393,17 @@ def mil_step(w, grads, beta: float, bag, sex, label, site, w_cls: float = 0.75, 
     events = None
     ev_objs = None
     if _TIMING is not None:
-        ev_objs = [torch.cuda.Event(enable_timing=True) for _ in range(18)]
-        for e in ev_objs:
-            e.record()                     # materialises the underlying hipEvent_t
-        events = (ctypes.c_void_p * 18)(*[e.cuda_event for e in ev_objs])
+        nev = 18 if _TIMING_LEVEL >= 2 else 2
+        ev_objs = [_take_event() for _ in range(nev)]
+        events = (ctypes.c_void_p * 18)(*([e.cuda_event for e in ev_objs] + [None] * (18 - nev)))
     _lib.check(lib.toad_mil_step_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag), _p(sex), _p(label), _p(site),
                                      float(w_cls), float(w_site), n, c, d, float(drop_p), int(seed), _p(x_amax), _p(loss), _p(logits),
                                      _p(slog), _p(ws), ws.numel(), events, _stream()), "toad_mil_step_f32")
     if ev_objs is not None:
         _TIMING.setdefault("pool_fwd", []).append((ev_objs[0], ev_objs[1]))
-        for i, name in enumerate(_GEMM_EVENT_NAMES):
-            _TIMING.setdefault(name, []).append((ev_objs[2 + 2 * i], ev_objs[3 + 2 * i]))
+        if len(ev_objs) == 18:
+            for i, name in enumerate(_GEMM_EVENT_NAMES):
+                _TIMING.setdefault(name, []).append((ev_objs[2 + 2 * i], ev_objs[3 + 2 * i]))
     return loss, logits, slog
 
 
