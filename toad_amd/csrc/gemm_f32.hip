@@ -106,8 +106,10 @@ static int h2_enabled() {
     if (v < 0) {
         const char *e = getenv("TOAD_GEMM_H2");             // A/B knob; default on
         v = e ? atoi(e) : 1;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_h2_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, H2_SMEM);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_h2_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, H2_SMEM);
+#define TOAD_H2_ATTR(P, A_, M_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_h2_big_kernel<P, A_, M_>), hipFuncAttributeMaxDynamicSharedMemorySize, H2_SMEM)
+        TOAD_H2_ATTR(false, false, false); TOAD_H2_ATTR(false, false, true); TOAD_H2_ATTR(true, false, false); TOAD_H2_ATTR(true, false, true);
+        TOAD_H2_ATTR(false, true, false); TOAD_H2_ATTR(false, true, true);
+#undef TOAD_H2_ATTR
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_h2_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM);
     }
     return v;
@@ -152,12 +154,14 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
                         const float *mask_src, H2Pool pool, float *slabs, float *y_amax, hipStream_t st, const char *what) {
     const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
     if (pool.T > 0 && addend) { set_error("%s: an addend buffer and the recomputed pooling addend are mutually exclusive", what); return TOAD_EINVAL; }
-    if (pool.T > 0)
-        hipLaunchKernelGGL(gemm_nt_h2_big_kernel<true>, dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, a_amax, planes, binv, C, ldc, (int)M,
-                           (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL(gemm_nt_h2_big_kernel<false>, dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, a_amax, planes, binv, C, ldc, (int)M,
-                           (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, tiles_m, tiles_n);
+#define TOAD_LAUNCH_H2(P, A_, M_)                                                                                                     \
+    hipLaunchKernelGGL((gemm_nt_h2_big_kernel<P, A_, M_>), dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, a_amax, planes, binv, C, ldc, (int)M, \
+                       (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, tiles_m, tiles_n)
+    const bool msk = mask_src != nullptr;
+    if (pool.T > 0) { if (msk) TOAD_LAUNCH_H2(true, false, true); else TOAD_LAUNCH_H2(true, false, false); }
+    else if (addend) { if (msk) TOAD_LAUNCH_H2(false, true, true); else TOAD_LAUNCH_H2(false, true, false); }
+    else { if (msk) TOAD_LAUNCH_H2(false, false, true); else TOAD_LAUNCH_H2(false, false, false); }
+#undef TOAD_LAUNCH_H2
     int rc = check_launch(what);
     if (rc) return rc;
     int max_rem = 0;                                   // fix-up grid: only as many tile rows as some XCD has remainder tiles
