@@ -51,6 +51,11 @@ int toad_absmax_rows256_f32(const float *X, int64_t M, int64_t K, float *amax, v
 /* 1 when the persistent fp16 two-piece kernel serves an [M,K] x [N,K]^T product (K % 32 == 0, N % 4 == 0, M*K*4 < 2^32);
  * other shapes run on the older exact-fp32 kernels (same results to fp32 round-off). */
 int toad_linear_h2_ok(int64_t M, int64_t N, int64_t K);
+/* One-bit image of a ReLU output Y[M,N] (= the mask of its backward): 8 KB per 256 x 256 tile, written by the forward GEMM's
+ * epilogue (relu_bits_out) and read back by the dgrad of the same layer (relu_bits) with the identical tile / lane mapping, so
+ * the dgrad epilogue reads 1/32 of the bytes an fp32 relu_src costs. Only whole tiles of the persistent kernel use it; the
+ * caller still passes relu_src (remainder tiles, other kernels). Both calls must see the same M and the same N (= dgrad's K). */
+size_t toad_relu_bits_bytes(int64_t M, int64_t N);
 
 /* Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]).   bias may be NULL.
  * Replaces nn.Linear(+nn.ReLU): models/model_toad.py:59 and :62 (trunk, act=RELU) and the
@@ -61,12 +66,13 @@ int toad_linear_h2_ok(int64_t M, int64_t N, int64_t K);
  * Requires K % 4 == 0. `ws` (toad_linear_ws_bytes, also used by toad_linear_dgrad_f32) holds the fp32 slabs of
  * K-split remainder tiles of the persistent 256x256 kernel, the split weight planes and, when x_amax == NULL, the
  * measured abs-max array; with ws == NULL, or K % 32 != 0, the generic 128x128 kernel runs instead.
- * x_amax: abs-max array of X or NULL.  y_amax: receives the abs-max array of Y, or NULL. */
+ * x_amax: abs-max array of X or NULL.  y_amax: receives the abs-max array of Y, or NULL.
+ * relu_bits_out (act = RELU, toad_linear_h2_ok shapes): receives the one-bit image of Y (toad_relu_bits_bytes), or NULL. */
 size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K);
 int toad_linear_act_fwd_f32(const float *X, const float *W, const float *bias, float *Y,
                             int64_t M, int64_t K, int64_t N, int act,
                             float drop_p, uint64_t drop_seed,
-                            const float *x_amax, float *y_amax,
+                            const float *x_amax, float *y_amax, uint64_t *relu_bits_out,
                             void *ws, size_t ws_bytes, void *stream);
 
 /* dX[M,K] = (dY[M,N] W[N,K] + addend[M,K] + pool[M,K]) * (relu_src[M,K] > 0) * mask_scale
@@ -80,12 +86,13 @@ int toad_linear_act_fwd_f32(const float *X, const float *W, const float *bias, f
  * Needs toad_linear_h2_ok(M, K, N) and a workspace.
  * Replaces autograd's mm backward + threshold_backward behind loss.backward()
  * (utils/core_utils_mtl_concat.py:231) for models/model_toad.py:62 and :21,:25.
- * Requires N % 4 == 0.  dy_amax: abs-max array of dY or NULL.  dx_amax: receives the abs-max array of dX, or NULL. */
+ * Requires N % 4 == 0.  dy_amax: abs-max array of dY or NULL.  dx_amax: receives the abs-max array of dX, or NULL.
+ * relu_bits: the one-bit image of relu_src written by the forward of this layer, or NULL. */
 int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend,
                           const float *relu_src, float mask_scale, float *dX,
                           int64_t M, int64_t N, int64_t K,
                           const float *pool_a_raw, const float *pool_stats, const float *pool_dM, int pool_T,
-                          const float *dy_amax, float *dx_amax,
+                          const float *dy_amax, float *dx_amax, const uint64_t *relu_bits,
                           void *ws, size_t ws_bytes, void *stream);
 
 /* dW[N,K] = beta*dW + dY[M,N]^T X[M,K];  db[N] = beta*db + column sums of dY (db may be NULL).
@@ -271,13 +278,14 @@ int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float *const *wei
  *   x_amax         : abs-max array of X (toad_absmax_rows256_f32) or NULL = measured inside the call.
  *
  * Memory. `arena` (toad_mil_arena_bytes) receives everything the backward needs and everything the caller reads:
- * toad_mil_arena_layout() returns the byte offset of each tensor in it, in this order (MIL_ARENA_SLOTS = 16 entries):
+ * toad_mil_arena_layout() returns the byte offset of each tensor in it, in this order (TOAD_MIL_ARENA_SLOTS entries):
  *   0 H1 [N,512]  1 H [N,512]  2 P [N,2D]  3 A_raw [N,2]  4 stats [2,2]  5 M [2,512]  6 Mcat [2,513]
  *   7 logits [C]  8 Y_prob [C]  9 Y_hat (int64)  10 site_logits [2]  11 site_prob [2]  12 site_hat (int64)
  *   13 x_amax  14 h1_amax  15 h_amax   (abs-max arrays, toad_amax_floats(N) floats each)
+ *   16 h1_bits  17 h_bits              (one-bit ReLU images, toad_relu_bits_bytes(N, 512) bytes each)
  * `scratch` (toad_mil_scratch_bytes) is temporary (GEMM slabs, weight planes, gradients of activations): it can be one
  * buffer reused by every call on a stream. */
-#define TOAD_MIL_ARENA_SLOTS 16
+#define TOAD_MIL_ARENA_SLOTS 18
 size_t toad_mil_buffer_align(int64_t N);   /* offsets are relative to `arena` rounded up to this power of two (the byte counts include the slack) */
 size_t toad_mil_arena_bytes(int64_t N, int C, int D);
 int toad_mil_arena_layout(int64_t N, int C, int D, int64_t *offsets /* [TOAD_MIL_ARENA_SLOTS] */);

@@ -30,7 +30,7 @@ def test_library_exports_every_header_symbol():
 def test_argument_errors_are_reported_without_a_gpu():
     from toad_amd import _lib
     lib = _lib.load()
-    rc = lib.toad_linear_act_fwd_f32(None, None, None, None, 4, 4, 4, 0, 0.0, 0, None, None, None, 0, None)
+    rc = lib.toad_linear_act_fwd_f32(None, None, None, None, 4, 4, 4, 0, 0.0, 0, None, None, None, None, 0, None)
     assert rc == -1 and b"null pointer" in lib.toad_last_error()
     # ABI v7: whole-slide entry points and the abs-max plumbing validate before touching the device
     import ctypes
@@ -42,7 +42,8 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.toad_linear_h2_ok(100000, 512, 1000) == 0 and lib.toad_linear_h2_ok(2_000_000, 512, 1024) == 0
     assert lib.toad_mil_arena_bytes(1000, 18, 384) > 1000 * (512 + 512 + 768 + 2) * 4
     assert lib.toad_mil_arena_bytes(1000, 18, 100) == 0 and lib.toad_mil_scratch_bytes(0, 18, 384) == 0
-    offs = (ctypes.c_int64 * 16)()
+    assert lib.toad_relu_bits_bytes(100000, 512) == 391 * 2 * 8192 and lib.toad_relu_bits_bytes(1, 4) == 8192
+    offs = (ctypes.c_int64 * 18)()
     assert lib.toad_mil_arena_layout(100000, 18, 384, offs) == 0
     o = list(offs)
     assert o[0] == 0 and all(b > a for a, b in zip(o, o[1:])) and all(x % (1 << 21) == 0 for x in o[:4]) and o[15] - o[14] == 391 * 4

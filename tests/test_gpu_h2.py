@@ -250,3 +250,20 @@ def test_flat_adam_state_round_trip_and_stale_buffer_guard(cuda):
     model.flatten_parameters()                                  # re-homes every parameter in a NEW flat buffer
     with pytest.raises(RuntimeError, match="flat parameter buffer was replaced"):
         dp.accumulate([], 1)
+
+
+@pytest.mark.parametrize("m", [1, 300, 4096, 70000])
+def test_one_bit_relu_image_gives_the_fp32_mask_result(cuda, m):
+    """The forward epilogue's one-bit image of its ReLU output, read back by the dgrad of the same layer (same M, same width),
+    gives bitwise the result of masking with the fp32 activations - whole tiles read the bits, remainder tiles the floats."""
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(m + 5)
+    x = torch.randn(m, 1024, generator=g).to(cuda); w = (torch.randn(512, 1024, generator=g) * 0.05).to(cuda); b = torch.randn(512, generator=g).to(cuda)
+    y, ya, bits = ops.linear_act_fwd(x, w, b, 1, drop_p=0.25, drop_seed=77, want_bits=True)      # ReLU + dropout zeros
+    y_plain = ops.linear_act_fwd(x, w, b, 1, drop_p=0.25, drop_seed=77)
+    assert torch.equal(y, y_plain) and bits.numel() == ops.relu_bits_bytes(m, 512)
+    dy = torch.randn(m, 768, generator=g).to(cuda); w2t = ops.transpose((torch.randn(768, 512, generator=g) * 0.05).to(cuda))
+    a = ops.linear_dgrad(dy, w2t, relu_src=y, mask_scale=4.0 / 3.0, relu_bits=bits)
+    r = ops.linear_dgrad(dy, w2t, relu_src=y, mask_scale=4.0 / 3.0)
+    assert torch.equal(a, r)
+    assert (a == 0).float().mean().item() > 0.5                                                   # the mask really masks

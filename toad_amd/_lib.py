@@ -23,8 +23,9 @@ SIGNATURES = {
     "toad_absmax_rows256_f32": (I, [P, I64, I64, P, P]),
     "toad_linear_h2_ok": (I, [I64, I64, I64]),
     "toad_linear_ws_bytes": (SZ, [I64, I64, I64]),
-    "toad_linear_act_fwd_f32": (I, [P, P, P, P, I64, I64, I64, I, F, U64, P, P, P, SZ, P]),
-    "toad_linear_dgrad_f32": (I, [P, P, P, P, F, P, I64, I64, I64, P, P, P, I, P, P, P, SZ, P]),
+    "toad_relu_bits_bytes": (SZ, [I64, I64]),
+    "toad_linear_act_fwd_f32": (I, [P, P, P, P, I64, I64, I64, I, F, U64, P, P, P, P, SZ, P]),
+    "toad_linear_dgrad_f32": (I, [P, P, P, P, F, P, I64, I64, I64, P, P, P, I, P, P, P, P, SZ, P]),
     "toad_dropout_mask_f32": (I, [P, I64, F, U64, P]),
     "toad_linear_wgrad_ws_bytes": (SZ, [I64, I64, I64]),
     "toad_linear_wgrad_f32": (I, [P, P, P, P, I64, I64, I64, F, P, P, P, SZ, P]),

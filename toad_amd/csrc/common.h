@@ -97,7 +97,8 @@ int launch_split_h2(const H2Operand *ops, int n, float *zero, int zero_n, hipStr
 int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax, bool zero, hipStream_t st, const char *what);
 int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C,
                  int64_t ldc, int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
-                 const float *mask_src, H2Pool pool, float *slabs, float *y_amax, hipStream_t st, const char *what);
+                 const float *mask_src, const unsigned long long *mask_bits, H2Pool pool, float *slabs, float *y_amax,
+                 unsigned long long *bits_out, hipStream_t st, const char *what);
 int launch_pool_bwd(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *A_raw, const float *stats,
                     const float *M, const float *dM, const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH, float *dWc, float *dbc,
                     float beta, float *dp_amax, bool zero_amax, void *ws, size_t ws_bytes, int64_t N, int L, int D, int T, float drop_p,

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
             }
         }
         if (dp_amax) {
-            // The abs-max array only has to BOUND |dP| from above (it picks a power-of-two scale with 2 bits of headroom to spare
+            // (dp_amax here = the fine table in the workspace.) The abs-max array only has to BOUND |dP| from above (it picks a power-of-two scale with 2 bits of headroom to spare
             // per 4x of slack), so instead of reducing 24 stored values per lane it uses, per row,
             //   |dPa|, |dPb| <= |dg| ka kb,  |dg| <= sum_t |dS_t| max_e |Wc[t,e]|     (|a|, b, 1-a^2 <= 1; ka, kb <= 1/(1-p))
             // which every lane of the row already holds: one cross-row exchange and one atomic per wave step. A step's rows lie
@@ -447,7 +447,9 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
             bound = valid ? bound : 0.f;
             if (RPW == 2) bound = __builtin_fmaxf(bound, __shfl_xor(bound, 32));
             else bound = h2_wave_max(bound);
-            if (lane == 0) h2_atomic_amax(dp_amax + (tile * ROWS_PER_BLOCK_STEP) / H2_ROWBLK, bound);
+            // one plain store per wave step into a fine-grained table; bwd_partial_reduce_kernel folds 128 entries into each
+            // 256-row slot. (Device-scope atomics bypass the per-XCD L2s: 50,000 of them cost this kernel 30-40 us at N = 100k.)
+            if (lane == 0) dp_amax[tile * NW + wave] = bound;
         }
     }
 
@@ -485,9 +487,23 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
 // block = 4 outputs x 64 partial slices, fixed summation order.
 __global__ __launch_bounds__(256) void bwd_partial_reduce_kernel(const float *__restrict__ partials, int G, int64_t rec,
                                                                   int n_w, int n_b, float *dWc, float *dbc,
-                                                                  float beta) {
+                                                                  float beta, int nred, const float *__restrict__ fine,
+                                                                  int n_fine, float *__restrict__ dp_amax) {
     __shared__ float red[64][4];
-    const int tid = threadIdx.x, o = tid & 3, slice = tid >> 2;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= nred) {
+        // extra workgroups: abs-max slot of 256-row block rb = max over its 32 eight-row steps x NW waves of the fine table
+        constexpr int PER = (H2_ROWBLK / ROWS_PER_BLOCK_STEP) * NW;
+        const int rb = blockIdx.x - nred;
+        float v = 0.f;
+        for (int e = tid; e < PER; e += 256) { const int i = rb * PER + e; if (i < n_fine) v = __builtin_fmaxf(v, fine[i]); }
+        v = h2_wave_max(v);
+        if ((tid & 63) == 0) red[tid >> 6][0] = v;
+        __syncthreads();
+        if (tid == 0) dp_amax[rb] = __builtin_fmaxf(__builtin_fmaxf(red[0][0], red[1][0]), __builtin_fmaxf(red[2][0], red[3][0]));
+        return;
+    }
+    const int o = tid & 3, slice = tid >> 2;
     const int e = blockIdx.x * 4 + o;
     float v = 0.f;
     if (e < n_w + n_b)
@@ -602,9 +618,12 @@ extern "C" int toad_gated_pool_fwd_f32(const float *Pa, const float *Pb, int64_t
     return check_launch(what);
 }
 
+static size_t bwd_partials_bytes(int64_t N, int D, int T) { return ((size_t)pool_grid(N) * (size_t)bwd_partial_floats(D, T) * sizeof(float) + 255) & ~(size_t)255; }
+static int64_t bwd_fine_floats(int64_t N) { return ((N + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP) * NW; }
 extern "C" size_t toad_gated_pool_bwd_ws_bytes(int64_t N, int L, int D, int T) {
     if (N <= 0 || !shape_ok(L, D, T)) return 0;
-    return (size_t)pool_grid(N) * (size_t)bwd_partial_floats(D, T) * sizeof(float);
+    // per-workgroup dWc / dbc partials, then the fine abs-max table (one float per wave per 8-row step)
+    return bwd_partials_bytes(N, D, T) + (size_t)bwd_fine_floats(N) * sizeof(float);
 }
 
 int toad::launch_pool_bwd(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *A_raw,
@@ -622,13 +641,15 @@ int toad::launch_pool_bwd(const float *Pa, const float *Pb, int64_t ldp, const f
     if (ws_bytes < toad_gated_pool_bwd_ws_bytes(N, L, D, T)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
     const int grid = pool_grid(N);
     static_assert(H2_ROWBLK % ROWS_PER_BLOCK_STEP == 0, "a block step must not straddle two abs-max blocks");
-    if (dp_amax && zero_amax) (void)hipMemsetAsync(dp_amax, 0, (size_t)((N + H2_ROWBLK - 1) / H2_ROWBLK) * sizeof(float), st);
-    launch_bwd(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, (float *)ws, dp_amax, (int)N, da, db);
+    (void)zero_amax;                                   // every slot is overwritten (no atomics): nothing to zero
+    float *fine = dp_amax ? reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + bwd_partials_bytes(N, D, T)) : nullptr;
+    launch_bwd(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, (float *)ws, fine, (int)N, da, db);
     int rc = check_launch(what);
     if (rc) return rc;
-    const int n = T * D + T;
-    hipLaunchKernelGGL(bwd_partial_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, st, (const float *)ws, grid,
-                       bwd_partial_floats(D, T), T * D, T, dWc, dbc, beta);
+    const int n = T * D + T, nred = (n + 3) / 4;
+    const int nblk = dp_amax ? (int)((N + H2_ROWBLK - 1) / H2_ROWBLK) : 0;
+    hipLaunchKernelGGL(bwd_partial_reduce_kernel, dim3(nred + nblk), dim3(256), 0, st, (const float *)ws, grid,
+                       bwd_partial_floats(D, T), T * D, T, dWc, dbc, beta, nred, (const float *)fine, (int)bwd_fine_floats(N), dp_amax);
     return check_launch(what);
 }
 

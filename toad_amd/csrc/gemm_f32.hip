@@ -107,8 +107,9 @@ static int h2_enabled() {
         const char *e = getenv("TOAD_GEMM_H2");             // A/B knob; default on
         v = e ? atoi(e) : 1;
 #define TOAD_H2_ATTR(P, A_, M_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_h2_big_kernel<P, A_, M_>), hipFuncAttributeMaxDynamicSharedMemorySize, H2_SMEM)
-        TOAD_H2_ATTR(false, false, false); TOAD_H2_ATTR(false, false, true); TOAD_H2_ATTR(true, false, false); TOAD_H2_ATTR(true, false, true);
-        TOAD_H2_ATTR(false, true, false); TOAD_H2_ATTR(false, true, true);
+        TOAD_H2_ATTR(false, false, 0); TOAD_H2_ATTR(false, false, 1); TOAD_H2_ATTR(false, false, 2);
+        TOAD_H2_ATTR(true, false, 0); TOAD_H2_ATTR(true, false, 1); TOAD_H2_ATTR(true, false, 2);
+        TOAD_H2_ATTR(false, true, 0); TOAD_H2_ATTR(false, true, 1);
 #undef TOAD_H2_ATTR
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_h2_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM);
     }
@@ -151,16 +152,20 @@ int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax,
 // C = epi(A . B^T) with pre-split B (planes + binv) and the abs-max array of A; y_amax (zeroed by the caller) receives the abs-max of C
 int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C,
                         int64_t ldc, int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
-                        const float *mask_src, H2Pool pool, float *slabs, float *y_amax, hipStream_t st, const char *what) {
+                        const float *mask_src, const unsigned long long *mask_bits, H2Pool pool, float *slabs, float *y_amax,
+                        unsigned long long *bits_out, hipStream_t st, const char *what) {
     const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
     if (pool.T > 0 && addend) { set_error("%s: an addend buffer and the recomputed pooling addend are mutually exclusive", what); return TOAD_EINVAL; }
+    // whole tiles read the one-bit ReLU image when the caller has it (mask_bits), the fix-up kernel always reads the fp32 mask_src
+    const float *msrc = mask_bits ? reinterpret_cast<const float *>(mask_bits) : mask_src;
 #define TOAD_LAUNCH_H2(P, A_, M_)                                                                                                     \
     hipLaunchKernelGGL((gemm_nt_h2_big_kernel<P, A_, M_>), dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, a_amax, planes, binv, C, ldc, (int)M, \
-                       (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, tiles_m, tiles_n)
-    const bool msk = mask_src != nullptr;
-    if (pool.T > 0) { if (msk) TOAD_LAUNCH_H2(true, false, true); else TOAD_LAUNCH_H2(true, false, false); }
-    else if (addend) { if (msk) TOAD_LAUNCH_H2(false, true, true); else TOAD_LAUNCH_H2(false, true, false); }
-    else { if (msk) TOAD_LAUNCH_H2(false, false, true); else TOAD_LAUNCH_H2(false, false, false); }
+                       (int)N, (int)K, bias, es, addend, msrc, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, bits_out, tiles_m, tiles_n)
+    const int msk = mask_bits ? 2 : (mask_src ? 1 : 0);
+    if (mask_bits && !mask_src) { set_error("%s: the one-bit ReLU image needs the fp32 relu_src as well (remainder tiles)", what); return TOAD_EINVAL; }
+    if (pool.T > 0) { if (msk == 2) TOAD_LAUNCH_H2(true, false, 2); else if (msk == 1) TOAD_LAUNCH_H2(true, false, 1); else TOAD_LAUNCH_H2(true, false, 0); }
+    else if (addend) { if (msk) { msrc = mask_src; TOAD_LAUNCH_H2(false, true, 1); } else TOAD_LAUNCH_H2(false, true, 0); }
+    else { if (msk == 2) TOAD_LAUNCH_H2(false, false, 2); else if (msk == 1) TOAD_LAUNCH_H2(false, false, 1); else TOAD_LAUNCH_H2(false, false, 0); }
 #undef TOAD_LAUNCH_H2
     int rc = check_launch(what);
     if (rc) return rc;
@@ -182,7 +187,8 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
                      const float *mask_src, void *ws, hipStream_t st, const char *what);
 static int launch_nt_auto(const float *A, int64_t lda, const float *a_amax, const float *B, int64_t ldb, float *C, int64_t ldc,
                           int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend, const float *mask_src,
-                          H2Pool pool, float *y_amax, void *ws, hipStream_t st, const char *what) {
+                          const unsigned long long *mask_bits, H2Pool pool, float *y_amax, unsigned long long *bits_out, void *ws,
+                          hipStream_t st, const char *what) {
     if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (bias && !aligned16(bias)) || (addend && !aligned16(addend)) ||
         (mask_src && !aligned16(mask_src))) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
     if (M > INT32_MAX - BM || N > INT32_MAX - BN || K > INT32_MAX - BK) { set_error("%s: dimension too large", what); return TOAD_ESHAPE; }
@@ -202,9 +208,10 @@ static int launch_nt_auto(const float *A, int64_t lda, const float *a_amax, cons
         }
         const H2Operand op{B, ldb, 1, N, K, planes, binv};
         if (int rc = launch_split_h2(&op, 1, nullptr, 0, st, what)) return rc;
-        return launch_nt_h2(A, lda, a_amax, planes, binv, C, ldc, M, N, K, bias, es, addend, mask_src, pool, slabs, y_amax, st, what);
+        return launch_nt_h2(A, lda, a_amax, planes, binv, C, ldc, M, N, K, bias, es, addend, mask_src, mask_bits, pool, slabs, y_amax, bits_out, st, what);
     }
     if (pool.T > 0) { set_error("%s: the recomputed pooling addend needs the h2 kernel (K %% 32 == 0, M*K*4 < 2^32, workspace)", what); return TOAD_ESHAPE; }
+    if (bits_out) { set_error("%s: the one-bit ReLU image is only produced by the h2 kernel (check toad_linear_h2_ok)", what); return TOAD_ESHAPE; }
     int rc = launch_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, es, addend, mask_src, ws, st, what);
     if (rc || !y_amax) return rc;
     hipLaunchKernelGGL(absmax_rows256_kernel, dim3(4, (int)h2_nblk(M)), dim3(256), 0, st, C, ldc, (int)M, (int)N, y_amax);
@@ -335,6 +342,10 @@ extern "C" size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 extern "C" int toad_linear_h2_ok(int64_t M, int64_t N, int64_t K) { return h2_nt_ok(M, N, K, K, N) ? 1 : 0; }
+extern "C" size_t toad_relu_bits_bytes(int64_t M, int64_t N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (size_t)((M + PB - 1) / PB) * (size_t)((N + PB - 1) / PB) * 8 * 2 * 64 * sizeof(unsigned long long);   // 8 KB per 256 x 256 tile
+}
 extern "C" size_t toad_amax_floats(int64_t rows) { return (size_t)h2_nblk(rows > 0 ? rows : 1); }
 
 extern "C" int toad_absmax_rows256_f32(const float *X, int64_t M, int64_t K, float *amax, void *stream) {
@@ -353,7 +364,8 @@ static int check_ws(void *ws, size_t ws_bytes, int64_t M, int64_t N, int64_t K, 
 
 extern "C" int toad_linear_act_fwd_f32(const float *X, const float *W, const float *bias, float *Y, int64_t M,
                                         int64_t K, int64_t N, int act, float drop_p, uint64_t drop_seed,
-                                        const float *x_amax, float *y_amax, void *ws, size_t ws_bytes, void *stream) {
+                                        const float *x_amax, float *y_amax, uint64_t *relu_bits_out, void *ws, size_t ws_bytes,
+                                        void *stream) {
     const char *what = "toad_linear_act_fwd_f32";
     if (!X || !W || !Y) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (act != TOAD_ACT_NONE && act != TOAD_ACT_RELU) { set_error("%s: bad act %d", what, act); return TOAD_EINVAL; }
@@ -361,8 +373,9 @@ extern "C" int toad_linear_act_fwd_f32(const float *X, const float *W, const flo
     if (int rc = check_ws(ws, ws_bytes, M, N, K, what)) return rc;
     if (M <= 0 || N <= 0 || K <= 0) { set_error("%s: non-positive dimension", what); return TOAD_EINVAL; }
     EpiScalars es{act == TOAD_ACT_RELU, 1.f, make_drop(drop_p, drop_seed)};
-    return launch_nt_auto(X, K, x_amax, W, K, Y, N, M, N, K, bias, es, nullptr, nullptr, H2Pool{nullptr, nullptr, nullptr, 0}, y_amax, ws,
-                          (hipStream_t)stream, what);
+    if (relu_bits_out && act != TOAD_ACT_RELU) { set_error("%s: relu_bits_out needs act = RELU", what); return TOAD_EINVAL; }
+    return launch_nt_auto(X, K, x_amax, W, K, Y, N, M, N, K, bias, es, nullptr, nullptr, nullptr, H2Pool{nullptr, nullptr, nullptr, 0}, y_amax,
+                          reinterpret_cast<unsigned long long *>(relu_bits_out), ws, (hipStream_t)stream, what);
 }
 
 extern "C" int toad_linear_act_res_fwd_f32(const float *X, const float *W, const float *bias, const float *residual, float *Y,
@@ -417,7 +430,8 @@ extern "C" int toad_stem_conv_s2d_f32(const float *Xs, const float *Wf, const fl
 extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend, const float *relu_src,
                                       float mask_scale, float *dX, int64_t M, int64_t N, int64_t K,
                                       const float *pool_a_raw, const float *pool_stats, const float *pool_dM, int pool_T,
-                                      const float *dy_amax, float *dx_amax, void *ws, size_t ws_bytes, void *stream) {
+                                      const float *dy_amax, float *dx_amax, const uint64_t *relu_bits, void *ws, size_t ws_bytes,
+                                      void *stream) {
     const char *what = "toad_linear_dgrad_f32";
     if (!dY || !WT || !dX) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (M <= 0 || N <= 0 || K <= 0) { set_error("%s: non-positive dimension", what); return TOAD_EINVAL; }
@@ -426,8 +440,9 @@ extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const flo
     if (int rc = check_ws(ws, ws_bytes, M, K, N, what)) return rc;
     // dX[M,K] = dY[M,N] . WT[K,N]^T : an NT product with reduction dim N
     EpiScalars es{0, mask_scale, make_drop(0.f, 0)};
-    return launch_nt_auto(dY, N, dy_amax, WT, N, dX, K, M, K, N, nullptr, es, addend, relu_src, H2Pool{pool_a_raw, pool_stats, pool_dM, pool_T},
-                          dx_amax, ws, (hipStream_t)stream, what);
+    if (relu_bits && (!relu_src || !h2_nt_ok(M, K, N, N, K) || !ws)) { set_error("%s: relu_bits needs relu_src, a workspace and the h2 kernel", what); return TOAD_EINVAL; }
+    return launch_nt_auto(dY, N, dy_amax, WT, N, dX, K, M, K, N, nullptr, es, addend, relu_src, reinterpret_cast<const unsigned long long *>(relu_bits),
+                          H2Pool{pool_a_raw, pool_stats, pool_dM, pool_T}, dx_amax, nullptr, ws, (hipStream_t)stream, what);
 }
 
 static bool tn_big_ok(int64_t M, int64_t N, int64_t K) {

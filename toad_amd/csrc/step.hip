@@ -27,7 +27,8 @@ struct Carver {
 };
 
 // ---- forward arena -------------------------------------------------------------------------------------------------
-enum { A_H1 = 0, A_H, A_P, A_ARAW, A_STATS, A_M, A_MCAT, A_LOGITS, A_YPROB, A_YHAT, A_SLOG, A_SPROB, A_SHAT, A_AMAX_X, A_AMAX_H1, A_AMAX_H };
+enum { A_H1 = 0, A_H, A_P, A_ARAW, A_STATS, A_M, A_MCAT, A_LOGITS, A_YPROB, A_YHAT, A_SLOG, A_SPROB, A_SHAT, A_AMAX_X, A_AMAX_H1, A_AMAX_H,
+       A_BITS_H1, A_BITS_H };
 static size_t arena_layout(const MilShape &s, int64_t *o) {
     const size_t big = big_align(s.N), N = (size_t)s.N;
     const size_t nb = toad_amax_floats(s.N) * sizeof(float);
@@ -48,6 +49,8 @@ static size_t arena_layout(const MilShape &s, int64_t *o) {
     o[A_AMAX_X] = c.take(nb, 256);        // the three arrays are adjacent: the weight-split launch zeroes them in one go
     o[A_AMAX_H1] = c.take(nb, 4);
     o[A_AMAX_H] = c.take(nb, 4);
+    o[A_BITS_H1] = c.take(toad_relu_bits_bytes(s.N, kL), 4096);      // one-bit ReLU images of H1 and H (8 KB per 256 x 256 tile)
+    o[A_BITS_H] = c.take(toad_relu_bits_bytes(s.N, kL), 4096);
     return up(c.off, 256);
 }
 
@@ -109,6 +112,7 @@ static Scratch scratch_layout(const MilShape &s, char *base) {
 struct Fwd {                       // typed view of the arena
     float *H1, *H, *P, *A_raw, *stats, *M, *Mcat, *logits, *yprob; int64_t *yhat; float *slog, *sprob; int64_t *shat;
     float *amax_x, *amax_h1, *amax_h;
+    unsigned long long *bits_h1, *bits_h;
 };
 static Fwd arena_view(const MilShape &s, char *base) {
     int64_t o[TOAD_MIL_ARENA_SLOTS];
@@ -119,6 +123,7 @@ static Fwd arena_view(const MilShape &s, char *base) {
     f.logits = (float *)(base + o[A_LOGITS]); f.yprob = (float *)(base + o[A_YPROB]); f.yhat = (int64_t *)(base + o[A_YHAT]);
     f.slog = (float *)(base + o[A_SLOG]); f.sprob = (float *)(base + o[A_SPROB]); f.shat = (int64_t *)(base + o[A_SHAT]);
     f.amax_x = (float *)(base + o[A_AMAX_X]); f.amax_h1 = (float *)(base + o[A_AMAX_H1]); f.amax_h = (float *)(base + o[A_AMAX_H]);
+    f.bits_h1 = (unsigned long long *)(base + o[A_BITS_H1]); f.bits_h = (unsigned long long *)(base + o[A_BITS_H]);
     return f;
 }
 
@@ -157,13 +162,13 @@ static int forward_body(const MilShape &s, const Params &p, const float *X, cons
         TOAD_TRY(launch_split_h2(ops, 3, f.amax_x, nz, st, what));
         if (x_amax) (void)hipMemcpyAsync(f.amax_x, x_amax, toad_amax_floats(N) * sizeof(float), hipMemcpyDeviceToDevice, st);
         else TOAD_TRY(launch_absmax(X, kL0, N, kL0, f.amax_x, false, st, what));
-        ev(2); TOAD_TRY(launch_nt_h2(X, kL0, f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nopool, w.slabs, f.amax_h1, st, what)); ev(3);
-        ev(4); TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nopool, w.slabs, f.amax_h, st, what)); ev(5);
-        ev(6); TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nopool, w.slabs, nullptr, st, what)); ev(7);
+        ev(2); TOAD_TRY(launch_nt_h2(X, kL0, f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h1, f.bits_h1, st, what)); ev(3);
+        ev(4); TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h, f.bits_h, st, what)); ev(5);
+        ev(6); TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nullptr, nopool, w.slabs, nullptr, nullptr, st, what)); ev(7);
     } else {       // shapes beyond the persistent kernels' 32-bit offsets (> 1 M patches): the per-op entry points pick their kernels
-        ev(2); TOAD_TRY(toad_linear_act_fwd_f32(X, p.w1, p.b1, f.H1, N, kL0, kL, TOAD_ACT_RELU, drop_p, ds.s1, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(3);
-        ev(4); TOAD_TRY(toad_linear_act_fwd_f32(f.H1, p.w2, p.b2, f.H, N, kL, kL, TOAD_ACT_RELU, drop_p, ds.s2, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(5);
-        ev(6); TOAD_TRY(toad_linear_act_fwd_f32(f.H, p.wab, p.bab, f.P, N, kL, D2, TOAD_ACT_NONE, 0.f, 0, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(7);
+        ev(2); TOAD_TRY(toad_linear_act_fwd_f32(X, p.w1, p.b1, f.H1, N, kL0, kL, TOAD_ACT_RELU, drop_p, ds.s1, nullptr, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(3);
+        ev(4); TOAD_TRY(toad_linear_act_fwd_f32(f.H1, p.w2, p.b2, f.H, N, kL, kL, TOAD_ACT_RELU, drop_p, ds.s2, nullptr, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(5);
+        ev(6); TOAD_TRY(toad_linear_act_fwd_f32(f.H, p.wab, p.bab, f.P, N, kL, D2, TOAD_ACT_NONE, 0.f, 0, nullptr, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(7);
     }
     if (attention_only) {
         TOAD_TRY(toad_gated_pool_fwd_f32(f.P, f.P + s.D, D2, nullptr, p.wc, p.bc, f.A_raw, nullptr, nullptr, nullptr, 0, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st));
@@ -195,14 +200,14 @@ static int backward_body(const MilShape &s, const Params &p, float *const *grads
                                  grads[6], grads[7], beta, w.amax_dP, false, w.poolb_ws, w.poolb_ws_bytes, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st));
         ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what)); ev(9);
         // dZ2 = (dP Wab + dH_pool) * (H > 0): the pooling gradient dH_pool is recomputed in the epilogue from A_raw, stats, dM
-        ev(10); TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, nullptr, f.H,
-                                      H2Pool{f.A_raw, f.stats, dM, kT}, w.slabs, w.amax_dZ2, st, what)); ev(11);
+        ev(10); TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, nullptr, f.H, f.bits_h,
+                                      H2Pool{f.A_raw, f.stats, dM, kT}, w.slabs, w.amax_dZ2, nullptr, st, what)); ev(11);
         ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws, st, what)); ev(13);
-        ev(14); TOAD_TRY(launch_nt_h2(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, nopool,
-                                      w.slabs, w.amax_dZ1, st, what)); ev(15);
+        ev(14); TOAD_TRY(launch_nt_h2(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, f.bits_h1, nopool,
+                                      w.slabs, w.amax_dZ1, nullptr, st, what)); ev(15);
         ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, X, f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws, st, what)); ev(17);
-        if (dX) TOAD_TRY(launch_nt_h2(w.dZ1, kL, w.amax_dZ1, w.planes[W_1T], w.binv[W_1T], dX, kL0, N, kL0, kL, nullptr, plain, nullptr, nullptr, nopool,
-                                      w.slabs, nullptr, st, what));
+        if (dX) TOAD_TRY(launch_nt_h2(w.dZ1, kL, w.amax_dZ1, w.planes[W_1T], w.binv[W_1T], dX, kL0, N, kL0, kL, nullptr, plain, nullptr, nullptr, nullptr, nopool,
+                                      w.slabs, nullptr, nullptr, st, what));
         return TOAD_OK;
     }
     // legacy sequence (per-op entry points, materialised dH_pool in the dZ2 buffer, explicit transposes)
@@ -211,14 +216,14 @@ static int backward_body(const MilShape &s, const Params &p, float *const *grads
                                      beta, nullptr, w.poolb_ws, w.poolb_ws_bytes, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st));
     ev(8); TOAD_TRY(toad_linear_wgrad_f32(w.dP, f.H, grads[4], grads[5], N, D2, kL, beta, nullptr, nullptr, w.wgrad_ws, w.wgrad_ws_bytes, st)); ev(9);
     TOAD_TRY(toad_transpose_f32(p.wab, w.t_abT, D2, kL, st));
-    ev(10); TOAD_TRY(toad_linear_dgrad_f32(w.dP, w.t_abT, dH, f.H, ds.mscale, dH, N, D2, kL, nullptr, nullptr, nullptr, 0, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(11);
+    ev(10); TOAD_TRY(toad_linear_dgrad_f32(w.dP, w.t_abT, dH, f.H, ds.mscale, dH, N, D2, kL, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(11);
     ev(12); TOAD_TRY(toad_linear_wgrad_f32(dH, f.H1, grads[2], grads[3], N, kL, kL, beta, nullptr, nullptr, w.wgrad_ws, w.wgrad_ws_bytes, st)); ev(13);
     TOAD_TRY(toad_transpose_f32(p.w2, w.t_2T, kL, kL, st));
-    ev(14); TOAD_TRY(toad_linear_dgrad_f32(dH, w.t_2T, nullptr, f.H1, ds.mscale, w.dZ1, N, kL, kL, nullptr, nullptr, nullptr, 0, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(15);
+    ev(14); TOAD_TRY(toad_linear_dgrad_f32(dH, w.t_2T, nullptr, f.H1, ds.mscale, w.dZ1, N, kL, kL, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(15);
     ev(16); TOAD_TRY(toad_linear_wgrad_f32(w.dZ1, X, grads[0], grads[1], N, kL, kL0, beta, nullptr, nullptr, w.wgrad_ws, w.wgrad_ws_bytes, st)); ev(17);
     if (dX) {
         TOAD_TRY(toad_transpose_f32(p.w1, w.t_1T, kL, kL0, st));
-        TOAD_TRY(toad_linear_dgrad_f32(w.dZ1, w.t_1T, nullptr, nullptr, 1.f, dX, N, kL, kL0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st));
+        TOAD_TRY(toad_linear_dgrad_f32(w.dZ1, w.t_1T, nullptr, nullptr, 1.f, dX, N, kL, kL0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st));
     }
     return TOAD_OK;
 }

@@ -52,6 +52,8 @@ class Saved:
     x_amax: Optional[torch.Tensor] = None    # abs-max arrays of x, h1, h (operand scales of the backward GEMMs)
     h1_amax: Optional[torch.Tensor] = None
     h_amax: Optional[torch.Tensor] = None
+    h1_bits: Optional[torch.Tensor] = None   # one-bit ReLU images of h1, h (the dgrad epilogues read these instead of 32x the bytes)
+    h_bits: Optional[torch.Tensor] = None
 
 
 def _stack_ab(w: Dict[str, torch.Tensor]):
@@ -64,15 +66,15 @@ def _stack_ab(w: Dict[str, torch.Tensor]):
 
 def trunk_scores(w: Dict[str, torch.Tensor], x: torch.Tensor, drop_p: float = 0.0, seed: int = 0, x_amax=None):
     """models/model_toad.py:59-64 trunk (+Dropout when training with dropout=True) + :21,:25 stacked
-    attention pre-activations. Returns (h1, h, p, (x_amax, h1_amax, h_amax))."""
+    attention pre-activations. Returns (h1, h, p, (x_amax, h1_amax, h_amax, h1_bits, h_bits))."""
     s1, s2, _, _ = drop_seeds(seed)
     if x_amax is None:
         x_amax = ops.absmax_rows256(x)
-    h1, h1_amax = ops.linear_act_fwd(x, w["w1"], w["b1"], ops.ACT_RELU, drop_p=drop_p, drop_seed=s1, x_amax=x_amax, want_amax=True)
-    h, h_amax = ops.linear_act_fwd(h1, w["w2"], w["b2"], ops.ACT_RELU, drop_p=drop_p, drop_seed=s2, x_amax=h1_amax, want_amax=True)
+    h1, h1_amax, h1_bits = ops.linear_act_fwd(x, w["w1"], w["b1"], ops.ACT_RELU, drop_p=drop_p, drop_seed=s1, x_amax=x_amax, want_bits=True)
+    h, h_amax, h_bits = ops.linear_act_fwd(h1, w["w2"], w["b2"], ops.ACT_RELU, drop_p=drop_p, drop_seed=s2, x_amax=h1_amax, want_bits=True)
     wab, bab = _stack_ab(w)
     p = ops.linear_act_fwd(h, wab, bab, ops.ACT_NONE, x_amax=h_amax)
-    return h1, h, p, (x_amax, h1_amax, h_amax)
+    return h1, h, p, (x_amax, h1_amax, h_amax, h1_bits, h_bits)
 
 
 def mil_forward(w: Dict[str, torch.Tensor], x: torch.Tensor, sex: torch.Tensor, drop_p: float = 0.0, seed: int = 0):
@@ -87,7 +89,7 @@ def mil_forward(w: Dict[str, torch.Tensor], x: torch.Tensor, sex: torch.Tensor, 
         h1, h, p, a_raw = e(w["w1"].shape[0]), e(l), e(2 * d), e(t)
         m = torch.zeros((t, l), dtype=torch.float32, device=x.device)
         stats = torch.zeros((t, 2), dtype=torch.float32, device=x.device)
-        amax = (None, None, None)
+        amax = (None, None, None, None, None)
     else:
         h1, h, p, amax = trunk_scores(w, x, drop_p, seed)
         _, _, sa, sb = drop_seeds(seed)
@@ -95,7 +97,7 @@ def mil_forward(w: Dict[str, torch.Tensor], x: torch.Tensor, sex: torch.Tensor, 
     mcat, logits, y_prob, y_hat, site_logits, site_prob, site_hat = ops.heads_fwd(
         m, sex, w["wcls"], w["bcls"], w["wsite"], w["bsite"])
     saved = Saved(x=x, h1=h1, h=h, p=p, a_raw=a_raw, stats=stats, m=m, mcat=mcat, drop_p=drop_p, seed=seed,
-                  x_amax=amax[0], h1_amax=amax[1], h_amax=amax[2])
+                  x_amax=amax[0], h1_amax=amax[1], h_amax=amax[2], h1_bits=amax[3], h_bits=amax[4])
     outs = dict(logits=logits, Y_prob=y_prob, Y_hat=y_hat, site_logits=site_logits, site_prob=site_prob,
                 site_hat=site_hat, A_nt=a_raw, features=mcat)
     return outs, saved
@@ -164,14 +166,15 @@ def mil_backward(w: Dict[str, torch.Tensor], s: Saved, dlogits: torch.Tensor, ds
     # dZ2 = (dP Wab + dH_pool) * (H > 0)
     if fused_pool:
         dz2, dz2_amax = ops.linear_dgrad(dp, ops.transpose(wab), relu_src=s.h, mask_scale=mscale, pool=(s.a_raw, s.stats, dm),
-                                         dy_amax=dp_amax, want_amax=True)
+                                         dy_amax=dp_amax, want_amax=True, relu_bits=s.h_bits)
     else:
         dz2, dz2_amax = ops.linear_dgrad(dp, ops.transpose(wab), addend=dh, relu_src=s.h, out=dh, mask_scale=mscale,
                                          dy_amax=dp_amax, want_amax=True)
     del dp
     g["w2"], g["b2"] = ops.linear_wgrad(dz2, s.h1, None if grads is None else grads["w2"],
                                         None if grads is None else grads["b2"], beta, dy_amax=dz2_amax, x_amax=s.h1_amax)
-    dz1, dz1_amax = ops.linear_dgrad(dz2, ops.transpose(w["w2"]), relu_src=s.h1, mask_scale=mscale, dy_amax=dz2_amax, want_amax=True)
+    dz1, dz1_amax = ops.linear_dgrad(dz2, ops.transpose(w["w2"]), relu_src=s.h1, mask_scale=mscale, dy_amax=dz2_amax, want_amax=True,
+                                     relu_bits=s.h1_bits)
     del dz2
     g["w1"], g["b1"] = ops.linear_wgrad(dz1, s.x, None if grads is None else grads["w1"],
                                         None if grads is None else grads["b1"], beta, dy_amax=dz1_amax, x_amax=s.x_amax)

@@ -131,10 +131,15 @@ def h2_ok(m: int, n: int, k: int) -> bool:
     return bool(_lib.load().toad_linear_h2_ok(int(m), int(n), int(k)))
 
 
+def relu_bits_bytes(m: int, n: int) -> int:
+    return int(_lib.load().toad_relu_bits_bytes(int(m), int(n)))
+
+
 def linear_act_fwd(x, w, b, act: int, out: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0,
-                   x_amax: Optional[torch.Tensor] = None, want_amax: bool = False):
+                   x_amax: Optional[torch.Tensor] = None, want_amax: bool = False, want_bits: bool = False):
     """Y = dropout_p(act(X W^T + b)); X [M,K], W [N,K], b [N] or None. drop_p = 0 disables dropout.
-    x_amax: abs-max array of X (else measured inside). want_amax: also return the abs-max array of Y -> (Y, y_amax)."""
+    x_amax: abs-max array of X (else measured inside). want_amax: also return the abs-max array of Y -> (Y, y_amax).
+    want_bits (act = RELU, h2_ok shapes): also return the one-bit image of Y for the dgrad of this layer -> (Y, y_amax, bits)."""
     _chk(x, "x"); _chk(w, "w"); _chk(b, "b", allow_none=True); _chk(x_amax, "x_amax", allow_none=True)
     m, k = x.shape
     n, k2 = w.shape
@@ -143,11 +148,14 @@ def linear_act_fwd(x, w, b, act: int, out: Optional[torch.Tensor] = None, drop_p
     y = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=x.device)
     _chk(y, "out")
     lib = _lib.load()
-    y_amax = torch.empty((amax_floats(m),), dtype=torch.float32, device=x.device) if want_amax else None
+    y_amax = torch.empty((amax_floats(m),), dtype=torch.float32, device=x.device) if (want_amax or want_bits) else None
+    bits = torch.empty((relu_bits_bytes(m, n),), dtype=torch.uint8, device=x.device) if (want_bits and h2_ok(m, n, k)) else None
     ws = _ws(lib.toad_linear_ws_bytes(m, n, k), x.device)
     with _timed("gemm_fwd"):
         _lib.check(lib.toad_linear_act_fwd_f32(_p(x), _p(w), _p(b), _p(y), m, k, n, act, float(drop_p), int(drop_seed),
-                                               _p(x_amax), _p(y_amax), _p(ws), ws.numel(), _stream()), "toad_linear_act_fwd_f32")
+                                               _p(x_amax), _p(y_amax), _p(bits), _p(ws), ws.numel(), _stream()), "toad_linear_act_fwd_f32")
+    if want_bits:
+        return y, y_amax, bits
     return (y, y_amax) if want_amax else y
 
 
@@ -160,11 +168,13 @@ def transpose(w: torch.Tensor) -> torch.Tensor:
 
 
 def linear_dgrad(dy, wt, addend=None, relu_src=None, out: Optional[torch.Tensor] = None, mask_scale: float = 1.0,
-                 pool=None, dy_amax: Optional[torch.Tensor] = None, want_amax: bool = False):
+                 pool=None, dy_amax: Optional[torch.Tensor] = None, want_amax: bool = False, relu_bits: Optional[torch.Tensor] = None):
     """dX = (dY W + addend + pool) * (relu_src > 0) * mask_scale; dY [M,N], wt = W^T [K,N].
     pool = (A_raw [M,T], stats [T,2], dM [T,K]): the attention-pooling gradient sum_t softmax(A_raw)[:,t] dM[t,:], recomputed in
-    the epilogue instead of read from an [M,K] buffer (needs h2_ok(M, K, N))."""
+    the epilogue instead of read from an [M,K] buffer (needs h2_ok(M, K, N)). relu_bits: the one-bit image of relu_src
+    (linear_act_fwd(..., want_bits=True) of the same layer)."""
     _chk(dy, "dy"); _chk(wt, "wt"); _chk(addend, "addend", allow_none=True); _chk(relu_src, "relu_src", allow_none=True)
+    _chk(relu_bits, "relu_bits", dtype=torch.uint8, allow_none=True)
     _chk(dy_amax, "dy_amax", allow_none=True)
     m, n = dy.shape
     k, n2 = wt.shape
@@ -188,8 +198,8 @@ def linear_dgrad(dy, wt, addend=None, relu_src=None, out: Optional[torch.Tensor]
     ws = _ws(lib.toad_linear_ws_bytes(m, k, n), dy.device)
     with _timed("gemm_dgrad"):
         _lib.check(lib.toad_linear_dgrad_f32(_p(dy), _p(wt), _p(addend), _p(relu_src), float(mask_scale), _p(dx), m, n, k,
-                                             _p(pa), _p(ps), _p(pd), pt, _p(dy_amax), _p(dx_amax), _p(ws), ws.numel(), _stream()),
-                   "toad_linear_dgrad_f32")
+                                             _p(pa), _p(ps), _p(pd), pt, _p(dy_amax), _p(dx_amax), _p(relu_bits), _p(ws), ws.numel(),
+                                             _stream()), "toad_linear_dgrad_f32")
     return (dx, dx_amax) if want_amax else dx
 
 
@@ -409,7 +419,7 @@ def mil_step(w, grads, beta: float, bag, sex, label, site, w_cls: float = 0.75, 
 
 # ---- model(data, sex) and loss.backward() as one C call each (toad_mil_fwd_f32 / toad_mil_bwd_f32) ---------------------
 ARENA_SLOTS = ("h1", "h", "p", "a_raw", "stats", "m", "mcat", "logits", "y_prob", "y_hat", "site_logits", "site_prob", "site_hat",
-               "x_amax", "h1_amax", "h_amax")
+               "x_amax", "h1_amax", "h_amax", "h1_bits", "h_bits")
 
 
 class MilArena:
