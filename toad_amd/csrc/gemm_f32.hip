@@ -111,7 +111,7 @@ static int h2_enabled() {
         TOAD_H2_ATTR(true, false, 0); TOAD_H2_ATTR(true, false, 1); TOAD_H2_ATTR(true, false, 2);
         TOAD_H2_ATTR(false, true, 0); TOAD_H2_ATTR(false, true, 1);
 #undef TOAD_H2_ATTR
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_h2_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_h2_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN2_SMEM);
     }
     return v;
 }
@@ -490,7 +490,7 @@ int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, co
             float *amax_ws = scales + 16;
             if (!dy_amax) { if ((rc = launch_absmax(dY, N, M, N, amax_ws, true, st, what))) return rc; dy_amax = amax_ws; }
             if (!x_amax) { float *a2 = amax_ws + h2_nblk(M) + 16; if ((rc = launch_absmax(X, K, M, K, a2, true, st, what))) return rc; x_amax = a2; }
-            hipLaunchKernelGGL(gemm_tn_h2_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, dy_amax, X, K, x_amax, slab, cs, scales,
+            hipLaunchKernelGGL(gemm_tn_h2_big_kernel, dim3(PB_GRID), dim3(512), TN2_SMEM, st, dY, N, dy_amax, X, K, x_amax, slab, cs, scales,
                                (int)M, (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
         } else if (tn_split)
             hipLaunchKernelGGL(gemm_tn_split_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, X, K, slab, cs, (int)M,
