@@ -446,3 +446,86 @@ def test_size_arg_small_end_to_end(cuda):
     for k, p in model.named_parameters():
         dev = (o_grads[k].double() - g64[k]).abs().max().item()
         assert_grad_close(p.grad, g64[k], 2e-5, grad_scale(g64, k), what=k, floor=4.0 * dev)
+
+
+# ---- ragged multi-slide forward (validate / summary) ------------------------------------------------------------------------
+
+def _ragged_slides(lens, c, seed=4321):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i, n in enumerate(lens):
+        out.append((torch.randn(n, 1024, generator=g).cuda(), torch.tensor([(5 * i) % c]).cuda(), torch.tensor([i % 2]).cuda(),
+                    torch.tensor([float((i // 2) % 2)]).cuda()))
+    return out
+
+
+def test_forward_many_equals_per_slide_forward(cuda):
+    """One pass of the trunk GEMMs over the concatenated ragged batch == model(data, sex) slide by slide (the reference's eval
+    loop, eval_utils_mtl_concat.py:88-91). Operand scales differ (256-row blocks of the concatenation), so fp32 round-off:
+    2e-5 of each tensor's own magnitude; the discrete outputs must agree exactly."""
+    from toad_amd import TOAD_fc_mtl_concat
+    torch.manual_seed(7)
+    c = 18
+    model = TOAD_fc_mtl_concat(n_classes=c); model.relocate(); model.eval()
+    lens = [1, 255, 256, 257, 700, 3, 2049, 64]
+    slides = _ragged_slides(lens, c)
+    many = model.forward_many([s[0] for s in slides], [s[3] for s in slides], return_features=True)
+    assert len(many) == len(lens)
+    for s, r in zip(slides, many):
+        with torch.no_grad():
+            one = model(s[0], s[3], return_features=True)
+        assert set(r) == set(one)
+        for k in ("logits", "Y_prob", "site_logits", "site_prob", "features", "A"):
+            assert r[k].shape == one[k].shape, k
+            tol = 2e-5 * max(one[k].abs().max().item(), 1e-6)
+            assert (r[k] - one[k]).abs().max().item() <= tol, (k, s[0].shape[0])
+        assert torch.equal(r["Y_hat"], one["Y_hat"]) and torch.equal(r["site_hat"], one["site_hat"])
+    with pytest.raises(ValueError):
+        model.forward_many([slides[0][0]], [])
+    with pytest.raises(ValueError):
+        model.forward_many([torch.empty(0, 1024).cuda()], [slides[0][3]])
+    assert model.forward_many([], []) == []
+
+
+def test_summary_and_validate_grouped_equal_ungrouped(cuda):
+    """summary / validate with the ragged grouping on (default) and off (the reference's one call per slide) tabulate the same
+    numbers, in loader order, including a slide larger than the group size (forwarded alone) and groups cut at the row budget."""
+    from types import SimpleNamespace
+    from toad_amd import TOAD_fc_mtl_concat
+    from toad_amd.eval import summary, forward_grouped
+    from toad_amd.train import validate
+    torch.manual_seed(8)
+    c = 5
+    model = TOAD_fc_mtl_concat(n_classes=c); model.relocate(); model.eval()
+    lens = [300, 5000, 40, 40, 1200, 7, 900, 2600]
+    slides = _ragged_slides(lens, c, seed=99)
+    loader = [(s[0], s[1], s[2], s[3]) for s in slides]
+    ids = ["s%d" % i for i in range(len(lens))]
+    args = SimpleNamespace(n_classes=c, micro_average=False)
+    a = summary(model, loader, args, slide_ids=ids, group_rows=0)
+    b = summary(model, loader, args, slide_ids=ids, group_rows=4096)
+    assert list(a["df"]["slide_id"]) == list(b["df"]["slide_id"]) == ids
+    for col in a["df"].columns:
+        if col == "slide_id":
+            continue
+        x, y = a["df"][col].to_numpy(dtype=float), b["df"][col].to_numpy(dtype=float)
+        assert abs(x - y).max() <= 2e-5, col
+    assert a["cls_test_error"] == b["cls_test_error"] and a["site_test_error"] == b["site_test_error"]
+    va, vb = validate(model, loader, c, group_rows=0), validate(model, loader, c, group_rows=4096)
+    assert va["slides"] == vb["slides"] == len(lens)
+    for k in ("cls_loss", "site_loss", "cls_error", "site_error"):
+        assert abs(va[k] - vb[k]) <= 2e-5 * max(abs(va[k]), 1.0), k
+    assert abs(va["prob"] - vb["prob"]).max() <= 2e-5
+    # grouping plan: [300] | [5000 alone] | [40, 40, 1200, 7, 900] | [2600]
+    calls = []
+
+    class Spy:
+        def __call__(self, data, sex):
+            calls.append([int(data.shape[0])]); return {}
+
+        def forward_many(self, bags, sexes):
+            calls.append([int(b.shape[0]) for b in bags]); return [{} for _ in bags]
+
+    got = [int(bt[0].shape[0]) for bt, _ in forward_grouped(Spy(), loader, 4096)]
+    assert got == lens
+    assert calls == [[300], [5000], [40, 40, 1200, 7, 900], [2600]]

@@ -75,12 +75,41 @@ def _cls_auc(labels: np.ndarray, probs: np.ndarray, n_classes: int, micro_averag
     return float(np.nanmean(np.array(aucs))), aucs
 
 
+def forward_grouped(model, batches: Iterable, group_rows: int = 131072):
+    """Yield ``(batch, result_dict)`` in loader order for an iterable of ``(data, label, site, sex)`` device batches.
+    Consecutive slides are collected until their patch counts reach ``group_rows`` and forwarded with ONE pass of the
+    trunk GEMMs (``TOAD_fc_mtl_concat.forward_many``): a 256-patch slide costs as many kernel launches as a 100k-patch one,
+    so the reference's per-slide loop (eval_utils_mtl_concat.py:88-91, core_utils_mtl_concat.py:281-284) is launch-bound on
+    small bags. A slide that alone reaches ``group_rows`` goes through ``model(data, sex)``; ``group_rows <= 0`` disables grouping."""
+    pending, rows = [], 0
+
+    def flush():
+        if len(pending) == 1:
+            b = pending[0]
+            yield b, model(b[0], b[3])
+        elif pending:
+            for b, r in zip(pending, model.forward_many([b[0] for b in pending], [b[3] for b in pending])):
+                yield b, r
+
+    for b in batches:
+        n = int(b[0].shape[0])
+        if group_rows <= 0 or n == 0 or n >= group_rows or not hasattr(model, "forward_many"):
+            yield from flush(); pending, rows = [], 0
+            yield b, model(b[0], b[3])
+            continue
+        if rows + n > group_rows and pending:
+            yield from flush(); pending, rows = [], 0
+        pending.append(b); rows += n
+    yield from flush()
+
+
 @torch.no_grad()
-def summary(model, loader: Iterable, args, slide_ids: Optional[Sequence] = None) -> Dict[str, object]:
+def summary(model, loader: Iterable, args, slide_ids: Optional[Sequence] = None, group_rows: int = 131072) -> Dict[str, object]:
     """Forward every slide once and tabulate (``eval_utils:65-177``).
 
     ``slide_ids`` defaults to ``loader.dataset.slide_data['slide_id']`` like the reference; pass a list when the
-    loader is a plain iterable. Returns the reference's keys: ``patient_results, cls_test_error, cls_auc,
+    loader is a plain iterable. ``group_rows`` > 0: consecutive slides are forwarded together (``forward_grouped``) until
+    their patch counts add up to it; 0 keeps the reference's one ``model(data, sex)`` per slide. Returns the reference's keys: ``patient_results, cls_test_error, cls_auc,
     cls_aucs, site_test_error, site_auc, loggers, df`` and ``top{k}_acc``.
     """
     import pandas as pd
@@ -92,9 +121,7 @@ def summary(model, loader: Iterable, args, slide_ids: Optional[Sequence] = None)
         slide_ids = loader.dataset.slide_data["slide_id"]
     ids = list(slide_ids)
     probs, site_probs, labels, sites, sexes, y_hats, s_hats = [], [], [], [], [], [], []
-    for batch in loader:
-        data, label, site, sex = _to_device(batch, device)
-        res = model(data, sex)
+    for (data, label, site, sex), res in forward_grouped(model, (_to_device(b, device) for b in loader), group_rows):
         cls_logger.log(res["Y_hat"], label)
         site_logger.log(res["site_hat"], site)
         probs.append(res["Y_prob"]); site_probs.append(res["site_prob"])

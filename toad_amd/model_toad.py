@@ -254,3 +254,48 @@ class TOAD_fc_mtl_concat(nn.Module):
                              "site_logits": site_logits, "site_prob": site_prob, "site_hat": site_hat,
                              "A": a_nt.t()})                      # pre-softmax scores, [2, N] (transpose view)
         return results_dict
+
+    @torch.no_grad()
+    def forward_many(self, bags, sexes, return_features=False):
+        """Forward-only pass over SEVERAL slides of different lengths (no reference counterpart: the reference's validate /
+        summary loops call ``model(data, sex)`` once per slide with batch size 1, utils/core_utils_mtl_concat.py:284,393 and
+        utils/eval_utils_mtl_concat.py:91). The rows of a bag never interact before the pooling, so the ragged batch is
+        concatenated to one [sum N, 1024] operand and the three trunk / attention GEMMs (99 % of the flops and most of the
+        launches of a small slide) run ONCE over it; the softmax pooling and the two heads then run per slide on row
+        ranges of the shared activations. Returns one result dict per slide with the keys of ``forward``.
+
+        Eval semantics only (dropout is not applied; gradients are not recorded). The GEMM operand scales are taken per
+        256-row block of the CONCATENATED operand, so the values agree with the one-slide path to fp32 round-off, not bitwise."""
+        if self.training and self._dropout:
+            raise RuntimeError("forward_many is an inference path: call model.eval() first (dropout would be skipped)")
+        bags = [b.contiguous() for b in bags]
+        if len(bags) != len(sexes):
+            raise ValueError("forward_many: one sex entry per bag")
+        if not bags:
+            return []
+        for b in bags:
+            _require_cuda(b, "bag")
+            if b.dim() != 2 or b.shape[0] == 0 or b.shape[1] != self.size_dict["big"][0]:
+                raise ValueError("forward_many: every bag must be a non-empty [N, 1024] tensor")
+        w = {k: v.detach() for k, v in self._weights().items()}
+        d = w["wc"].shape[1]
+        x = bags[0] if len(bags) == 1 else torch.cat(bags, 0)
+        h1, a1 = ops.linear_act_fwd(x, w["w1"], w["b1"], ops.ACT_RELU, want_amax=True)
+        h, a2 = ops.linear_act_fwd(h1, w["w2"], w["b2"], ops.ACT_RELU, x_amax=a1, want_amax=True)
+        del h1
+        p = ops.linear_act_fwd(h, w["wab"], w["bab"], ops.ACT_NONE, x_amax=a2)
+        out, off = [], 0
+        for b, sex in zip(bags, sexes):
+            n = b.shape[0]
+            a_raw, m, _ = ops.gated_pool_fwd(p[off:off + n], d, h[off:off + n], w["wc"], w["bc"])
+            _require_cuda(sex, "sex")
+            mcat, logits, y_prob, y_hat, s_logits, s_prob, s_hat = ops.heads_fwd(
+                m, sex.to(torch.float32).reshape(1).contiguous(), w["wcls"], w["bcls"], w["wsite"], w["bsite"])
+            res = {}
+            if return_features:
+                res["features"] = mcat
+            res.update({"logits": logits, "Y_prob": y_prob, "Y_hat": y_hat, "site_logits": s_logits, "site_prob": s_prob,
+                        "site_hat": s_hat, "A": a_raw.t()})
+            out.append(res)
+            off += n
+        return out

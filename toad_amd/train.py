@@ -89,7 +89,7 @@ def _auc(labels: np.ndarray, probs: np.ndarray, n_classes: int) -> float:
 
 
 @torch.no_grad()
-def validate(model, loader: Iterable, n_classes: int, loss_fn=None, with_auc: bool = True) -> Dict[str, object]:
+def validate(model, loader: Iterable, n_classes: int, loss_fn=None, with_auc: bool = True, group_rows: int = 131072) -> Dict[str, object]:
     """Forward-only pass (reference ``validate`` / ``summary``): losses, errors, per-slide probabilities, AUCs."""
     device = next(model.parameters()).device
     loss_fn = loss_fn or nn.CrossEntropyLoss()
@@ -98,9 +98,8 @@ def validate(model, loader: Iterable, n_classes: int, loss_fn=None, with_auc: bo
     sums = torch.zeros(4, dtype=torch.float64, device=device)
     probs, site_probs, labels, sites = [], [], [], []
     n = 0
-    for batch in loader:
-        data, label, site, sex = _to_device(batch, device)
-        res = model(data, sex)
+    from .eval import forward_grouped
+    for (data, label, site, sex), res in forward_grouped(model, (_to_device(b, device) for b in loader), group_rows):
         cls_logger.log(res["Y_hat"], label)
         site_logger.log(res["site_hat"], site)
         sums += torch.stack([loss_fn(res["logits"], label).double(), loss_fn(res["site_logits"], site).double(),
