@@ -74,3 +74,56 @@ def test_train_loop_tracks_oracle_sgd(cuda):
     ref_prob = torch.cat([x["Y_prob"] for x in o]).numpy()
     assert np.abs(v["prob"] - ref_prob).max() <= 1e-4
     assert v["slides"] == 6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+def test_fused_train_loop_equals_the_reference_sequence(cuda, opt):
+    """train_loop's fused route (one toad_mil_step_f32 per slide + the optimiser) against the reference's literal sequence
+    (model(data, sex), two CE modules, backward, step, zero_grad; core_utils_mtl_concat.py:201-234): same epoch statistics and
+    the same parameters after 7 slides - with the torch optimiser get_optim(flat=False) builds, and with the one-launch flat
+    optimiser of get_optim (flat=True). Also checks get_optim's error branch (utils/utils.py:68-69)."""
+    from types import SimpleNamespace
+    from toad_amd import TOAD_fc_mtl_concat
+    from toad_amd.optim import get_optim, FlatAdam, FlatSGD
+    from toad_amd.train import train_loop
+    c = 18
+    slides = []
+    for i, n in enumerate((120, 333, 64, 1025, 90, 500, 256)):
+        g = torch.Generator().manual_seed(700 + i)
+        slides.append((torch.randn(n, 1024, generator=g), torch.tensor([(7 * i) % c]), torch.tensor([i % 2]), torch.tensor([float(i % 2)])))
+    args = SimpleNamespace(opt=opt, lr=2e-3, reg=1e-5)
+
+    def run(flat, fused):
+        torch.manual_seed(21)
+        model = TOAD_fc_mtl_concat(n_classes=c); model.relocate()
+        o = get_optim(model, args, flat=flat)
+        assert isinstance(o, (FlatAdam, FlatSGD)) == flat
+        stats = [train_loop(e, model, slides, o, c, fused=fused) for e in range(2)]
+        return stats, model.flat_parameters().detach().cpu().clone()
+
+    ref_stats, ref_p = run(False, False)
+    for flat in (False, True):
+        stats, p = run(flat, True)
+        diff = (p - ref_p).abs()
+        if opt == "sgd":
+            assert diff.max().item() <= 2e-2 * args.lr, (flat, diff.max().item())
+        else:
+            # Adam's update is lr * m / (sqrt(v) + eps): an element whose gradient is round-off (the cancellation-dominated
+            # attention biases, never-hit class rows) steps by +-lr in a direction the last bit decides, so the bound on EVERY element
+            # is the trivial one (steps x lr); the typical element must agree to a small fraction of one step
+            assert diff.max().item() <= 2 * len(slides) * args.lr * 1.01, (flat, diff.max().item())
+            assert diff.median().item() <= 1e-3 * args.lr and (diff > 0.1 * args.lr).double().mean().item() <= 0.02, \
+                (flat, diff.median().item(), (diff > 0.1 * args.lr).double().mean().item())
+        for e, (a, b) in enumerate(zip(stats, ref_stats)):
+            assert a["slides"] == b["slides"] == len(slides)
+            rel = 2e-5 if (opt == "sgd" or e == 0) else 1e-3      # (Adam: the round-off-driven elements above feed the second epoch)
+            for k in ("cls_loss", "site_loss"):
+                assert abs(a[k] - b[k]) <= rel * max(abs(b[k]), 1.0), (k, e)
+            if opt == "sgd" or e == 0:
+                assert a["cls_error"] == b["cls_error"] and a["site_error"] == b["site_error"]
+                assert a["cls_acc"] == b["cls_acc"] and a["site_acc"] == b["site_acc"]
+    with pytest.raises(NotImplementedError):
+        get_optim(None, SimpleNamespace(opt="rmsprop", lr=1e-4, reg=0.0))
+    with pytest.raises(ValueError):
+        train_loop(0, TOAD_fc_mtl_concat(n_classes=c).cuda(), slides, None, c, loss_fn=torch.nn.CrossEntropyLoss(label_smoothing=0.1), fused=True)

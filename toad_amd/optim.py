@@ -7,6 +7,8 @@ unchanged (the drop-in path).
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 
 from . import _lib
@@ -22,10 +24,18 @@ class FlatAdam:
         self.m = torch.zeros_like(flat_param)
         self.v = torch.zeros_like(flat_param)
         self.t = 0
+        self.grad: Optional[torch.Tensor] = None       # bound gradient buffer for the argument-less step() of the harness loop
 
-    def step(self, flat_grad: torch.Tensor) -> None:
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        """No-op: the fused slide step overwrites the gradient buffer (beta = 0); kept so that the reference's loop body
+        (``optimizer.step(); optimizer.zero_grad()``, utils/core_utils_mtl_concat.py:233-234) runs unchanged."""
+
+    def step(self, flat_grad: Optional[torch.Tensor] = None) -> None:
         if not self.p.is_cuda:
             raise RuntimeError("FlatAdam runs on the HIP device only")
+        flat_grad = self.grad if flat_grad is None else flat_grad
+        if flat_grad is None:
+            raise RuntimeError("FlatAdam.step: no gradient buffer (pass one or bind it with .grad = buffer)")
         self.t += 1
         lib = _lib.load()
         _lib.check(lib.toad_adam_step_f32(self.p.data_ptr(), flat_grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
@@ -58,10 +68,17 @@ class FlatSGD:
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.buf = torch.zeros_like(flat_param) if momentum != 0.0 else None
         self.t = 0
+        self.grad: Optional[torch.Tensor] = None
 
-    def step(self, flat_grad: torch.Tensor) -> None:
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        """No-op (see FlatAdam.zero_grad)."""
+
+    def step(self, flat_grad: Optional[torch.Tensor] = None) -> None:
         if not self.p.is_cuda:
             raise RuntimeError("FlatSGD runs on the HIP device only")
+        flat_grad = self.grad if flat_grad is None else flat_grad
+        if flat_grad is None:
+            raise RuntimeError("FlatSGD.step: no gradient buffer (pass one or bind it with .grad = buffer)")
         self.t += 1
         lib = _lib.load()
         _lib.check(lib.toad_sgd_step_f32(self.p.data_ptr(), flat_grad.data_ptr(), None if self.buf is None else self.buf.data_ptr(),
@@ -76,3 +93,20 @@ class FlatSGD:
             self.buf.copy_(sd["buf"].to(self.buf.device).reshape(-1))
         self.t = int(sd["t"])
         self.lr, self.momentum, self.weight_decay = float(sd["lr"]), float(sd["momentum"]), float(sd["weight_decay"])
+
+
+def get_optim(model, args, flat: bool = True):
+    """``get_optim`` of the reference (utils/utils.py:63-70): ``args.opt`` in {"adam", "sgd"}, ``args.lr``, ``args.reg``.
+    ``flat`` (default): the one-launch HIP optimiser over the model's flat parameter buffer, which ``toad_amd.train.train_loop``
+    drives with the fused slide step; ``flat=False``: the reference's torch optimiser over ``model.parameters()``."""
+    if args.opt not in ("adam", "sgd"):
+        raise NotImplementedError
+    if not flat:
+        params = filter(lambda p: p.requires_grad, model.parameters())
+        if args.opt == "adam":
+            return torch.optim.Adam(params, lr=args.lr, weight_decay=args.reg)
+        return torch.optim.SGD(params, lr=args.lr, momentum=0.9, weight_decay=args.reg)
+    buf = model.flat_parameters()
+    if args.opt == "adam":
+        return FlatAdam(buf, lr=args.lr, weight_decay=args.reg)
+    return FlatSGD(buf, lr=args.lr, momentum=0.9, weight_decay=args.reg)

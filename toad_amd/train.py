@@ -42,16 +42,102 @@ def _to_device(batch, device):
             site.to(device, non_blocking=True), sex.float().to(device, non_blocking=True))
 
 
-def train_loop(epoch: int, model, loader: Iterable, optimizer, n_classes: int, loss_fn=None) -> Dict[str, object]:
-    """One epoch, one optimiser step per slide (the reference's batch size is 1, utils/utils.py:51-55)."""
+class _FusedGrads:
+    """The flat gradient buffer of a model and its per-slot views (what toad_mil_step_f32 writes), with every parameter's
+    ``.grad`` pointing into it so that a torch optimiser over ``model.parameters()`` reads the same memory."""
+
+    def __init__(self, model):
+        self.flat = model.flat_parameters()
+        self.flat_grad = torch.zeros_like(self.flat)
+        offs, _ = model.flat_offsets()
+        sp = model._slot_params()
+        self.views: Dict[str, torch.Tensor] = {}
+        for k, p in sp.items():
+            o, n = offs[k]
+            self.views[k] = self.flat_grad[o:o + n].view_as(p)
+        d, l = sp["wa"].shape
+        oa, ob = offs["wa"][0], offs["ba"][0]
+        self.views["wab"] = self.flat_grad[oa:oa + 2 * d * l].view(2 * d, l)
+        self.views["bab"] = self.flat_grad[ob:ob + 2 * d]
+        self.params = sp
+
+    def bind(self):
+        for k, p in self.params.items():
+            if p.grad is not self.views[k]:
+                p.grad = self.views[k]
+
+
+def _fused_grads(model) -> "_FusedGrads":
+    st = getattr(model, "_fused_grads", None)
+    if st is None or st.flat is not model.flat_parameters():
+        st = _FusedGrads(model)
+        model._fused_grads = st
+    return st
+
+
+def _fused_ok(model, optimizer, loss_fn) -> bool:
+    """The fused slide step computes exactly 0.75*CE(logits, label) + 0.25*CE(site_logits, site) with default CE settings
+    (core_utils_mtl_concat.py:213-215 with the loss_fn of :105)."""
+    from .model_toad import TOAD_fc_mtl_concat
+    if not isinstance(model, TOAD_fc_mtl_concat) or not next(model.parameters()).is_cuda:
+        return False
+    if loss_fn is not None:
+        if type(loss_fn) is not nn.CrossEntropyLoss or loss_fn.weight is not None or loss_fn.reduction != "mean" \
+                or getattr(loss_fn, "label_smoothing", 0.0) != 0.0 or loss_fn.ignore_index != -100:
+            return False
+    if any(not p.requires_grad for p in model.parameters()):
+        return False
+    return True
+
+
+def train_loop(epoch: int, model, loader: Iterable, optimizer, n_classes: int, loss_fn=None, fused: Optional[bool] = None) -> Dict[str, object]:
+    """One epoch, one optimiser step per slide (the reference's batch size is 1, utils/utils.py:51-55).
+
+    ``fused`` (default: whenever the model is the HIP TOAD module and the loss is the reference's plain cross-entropy): forward,
+    the weighted loss and the backward of a slide are ONE library call (``toad_mil_step_f32``) that writes the gradients into
+    a flat buffer every parameter's ``.grad`` aliases; the optimiser then steps as usual (a torch optimiser over
+    ``model.parameters()``, or the one-launch ``FlatAdam`` / ``FlatSGD`` of ``toad_amd.optim.get_optim``). The per-slide
+    numbers are those of the unfused sequence below (tests/test_gpu_model.py::test_fused_loss_path_equals_autograd_path);
+    what it removes is the host path of autograd + two CE modules + zero_grad, which at 256 patches costs three times the
+    GPU work. ``fused=False`` runs the reference's sequence literally."""
     device = next(model.parameters()).device
+    if fused is None:
+        fused = _fused_ok(model, optimizer, loss_fn)
+    elif fused and not _fused_ok(model, optimizer, loss_fn):
+        raise ValueError("train_loop(fused=True) needs the HIP TOAD module on the device and the default CrossEntropyLoss")
     loss_fn = loss_fn or nn.CrossEntropyLoss()
     model.train()
     cls_logger, site_logger = AccuracyLogger(n_classes, device), AccuracyLogger(2, device)
     sums = torch.zeros(4, dtype=torch.float64, device=device)      # cls loss, site loss, cls error, site error
     n = 0
+    if fused:
+        from . import ops
+        from .model_toad import _draw_dropout
+        from .optim import FlatAdam, FlatSGD
+        fg = _fused_grads(model)
+        flat_opt = isinstance(optimizer, (FlatAdam, FlatSGD))
+        if flat_opt and optimizer.p is not fg.flat:
+            raise RuntimeError("train_loop: the flat optimiser was built for a parameter buffer the model no longer uses")
+        if not flat_opt:
+            fg.bind()
     for batch in loader:
         data, label, site, sex = _to_device(batch, device)
+        if fused and data.shape[0] > 0:
+            w = {k: v.detach() for k, v in model._weights().items()}
+            drop_p, seed = _draw_dropout(model._dropout and model.training)
+            loss3, logits, slog = ops.mil_step(w, fg.views, 0.0, data.contiguous(), sex.reshape(1), label.reshape(1), site.reshape(1),
+                                               0.75, 0.25, drop_p, seed, want_logits=True)
+            y_hat, s_hat = logits.argmax(1), slog.argmax(1)
+            cls_logger.log(y_hat, label)
+            site_logger.log(s_hat, site)
+            sums += torch.stack([loss3[1].double(), loss3[2].double(), (y_hat != label.reshape(-1)).double().mean(),
+                                 (s_hat != site.reshape(-1)).double().mean()])
+            if flat_opt:
+                optimizer.step(fg.flat_grad)
+            else:
+                optimizer.step()                                      # reads the .grad views bound above; nothing to zero (beta = 0)
+            n += 1
+            continue
         res = model(data, sex)
         cls_loss = loss_fn(res["logits"], label)
         site_loss = loss_fn(res["site_logits"], site)
@@ -62,6 +148,23 @@ def train_loop(epoch: int, model, loader: Iterable, optimizer, n_classes: int, l
             sums += torch.stack([cls_loss.detach().double(), site_loss.detach().double(),
                                  (res["Y_hat"].reshape(-1) != label.reshape(-1)).double().mean(),   # calculate_error
                                  (res["site_hat"].reshape(-1) != site.reshape(-1)).double().mean()])
+        if fused:                                                     # an empty bag inside a fused epoch: autograd path, same buffers
+            from .optim import FlatAdam, FlatSGD
+            for p in model.parameters():
+                p.grad = None
+            loss.backward()
+            if isinstance(optimizer, (FlatAdam, FlatSGD)):
+                offs, _ = model.flat_offsets()
+                fg.flat_grad.zero_()
+                for k, p in fg.params.items():
+                    if p.grad is not None:
+                        fg.views[k].copy_(p.grad)
+                optimizer.step(fg.flat_grad)
+            else:
+                optimizer.step()
+            fg.bind()
+            n += 1
+            continue
         loss.backward()
         optimizer.step()
         optimizer.zero_grad()
