@@ -386,6 +386,17 @@ extern "C" int toad_linear_act_res_fwd_f32(const float *X, const float *W, const
     if (residual && (N % 4 != 0 || !aligned16(residual))) { set_error("%s: residual needs N %% 4 == 0 and 16-byte alignment", what); return TOAD_ESHAPE; }
     if (int rc = check_ws(ws, ws_bytes, M, N, K, what)) return rc;
     EpiScalars es{act == TOAD_ACT_RELU, 1.f, make_drop(0.f, 0)};
+    // Wide outputs (the extractor's 1x1 expansions / downsamples and its 256-channel 3x3 after im2col) run on the fp16 two-piece
+    // kernel of the MIL path: 3 MFMA terms per product instead of the split-bf16 kernel's 6. X's abs-max array is measured in `ws`
+    // (one read of X; the producers here are the narrow kernels, which do not emit it). Shapes the narrow tiles take (N <= 128,
+    // short-K residual GEMMs) keep them. TOAD_EXTRACT_H2=0: the round-1 dispatch.
+    static int ext_h2 = -1;
+    if (ext_h2 < 0) { const char *e = getenv("TOAD_EXTRACT_H2"); ext_h2 = e ? atoi(e) : 1; }
+    if (ext_h2 && h2_enabled() && ws && h2_nt_ok(M, N, K, K, N) && !narrow_ok(M, N, K, N, bias, residual, ws)) {
+        const H2Pool nopool{nullptr, nullptr, nullptr, 0};
+        return launch_nt_auto(X, K, nullptr, W, K, Y, N, M, N, K, bias, es, residual, nullptr, nullptr, nopool, nullptr, nullptr, ws,
+                              (hipStream_t)stream, what);
+    }
     return launch_nt(X, K, W, K, Y, N, M, N, K, bias, es, residual, nullptr, ws, (hipStream_t)stream, what);
 }
 
