@@ -172,8 +172,14 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
     int max_rem = 0;                                   // fix-up grid: only as many tile rows as some XCD has remainder tiles
     for (int x = 0; x < kNumXCD; ++x) { const NtPlan pl = nt_plan(x, tiles_m, tiles_n, (int)(K / BK)); if (pl.g > 1 && pl.rem > max_rem) max_rem = pl.rem; }
     if (max_rem > 0) {
-        hipLaunchKernelGGL(nt_fixup_h2_kernel, dim3(64, max_rem, kNumXCD), dim3(256), 0, st, (const float *)slabs, a_amax, binv, C, ldc,
-                           (int)M, (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, y_amax, tiles_m, tiles_n);
+        int rem_all = 0;
+        for (int x = 0; x < kNumXCD; ++x) { const NtPlan pl = nt_plan(x, tiles_m, tiles_n, (int)(K / BK)); if (pl.g > 1) rem_all += pl.rem; }
+        if (rem_all > 8)
+            hipLaunchKernelGGL(nt_fixup_h2_kernel<4>, dim3(16, max_rem, kNumXCD), dim3(256), 0, st, (const float *)slabs, a_amax, binv, C, ldc,
+                               (int)M, (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, y_amax, tiles_m, tiles_n);
+        else
+            hipLaunchKernelGGL(nt_fixup_h2_kernel<1>, dim3(64, max_rem, kNumXCD), dim3(256), 0, st, (const float *)slabs, a_amax, binv, C, ldc,
+                               (int)M, (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, y_amax, tiles_m, tiles_n);
         rc = check_launch(what);
     }
     return rc;
