@@ -146,7 +146,7 @@ int launch_split_h2(const H2Operand *ops, int n, float *zero, int zero_n, hipStr
 int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax, bool zero, hipStream_t st, const char *what) {
     const int nblk = (int)h2_nblk(M);
     if (zero) (void)hipMemsetAsync(amax, 0, (size_t)nblk * sizeof(float), st);
-    hipLaunchKernelGGL(absmax_rows256_kernel, dim3(nblk < 128 ? 16 : 4, nblk), dim3(256), 0, st, X, ld, (int)M, (int)K, amax);
+    hipLaunchKernelGGL(absmax_rows256_kernel, dim3(nblk <= 8 ? 16 : 4, nblk), dim3(256), 0, st, X, ld, (int)M, (int)K, amax);
     return check_launch(what);
 }
 // C = epi(A . B^T) with pre-split B (planes + binv) and the abs-max array of A; y_amax (zeroed by the caller) receives the abs-max of C
@@ -220,7 +220,7 @@ static int launch_nt_auto(const float *A, int64_t lda, const float *a_amax, cons
     if (bits_out) { set_error("%s: the one-bit ReLU image is only produced by the h2 kernel (check toad_linear_h2_ok)", what); return TOAD_ESHAPE; }
     int rc = launch_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, es, addend, mask_src, ws, st, what);
     if (rc || !y_amax) return rc;
-    hipLaunchKernelGGL(absmax_rows256_kernel, dim3(h2_nblk(M) < 128 ? 16 : 4, (int)h2_nblk(M)), dim3(256), 0, st, C, ldc, (int)M, (int)N, y_amax);
+    hipLaunchKernelGGL(absmax_rows256_kernel, dim3(h2_nblk(M) <= 8 ? 16 : 4, (int)h2_nblk(M)), dim3(256), 0, st, C, ldc, (int)M, (int)N, y_amax);
     return check_launch(what);
 }
 
