@@ -177,10 +177,13 @@ def cpu_baseline_pool(n_patches: int, budget_s: float = 20.0):
             "ms_per_launch": round(med * 1e3, 3)}
 
 
+BAG_DTYPE = torch.float32          # --bag-dtype fp16: bags stored in half precision (a side experiment, never the headline)
+
+
 def make_slide(idx: int, n: int, dev):
     """SURVEY.md 8(d) synthetic inputs: N(0,1) bag seeded by the slide index, generated on the device."""
     g = torch.Generator(device=dev).manual_seed(1000 + idx)
-    bag = torch.randn(n, L0, device=dev, generator=g)
+    bag = torch.randn(n, L0, device=dev, generator=g).to(BAG_DTYPE)
     return (bag, torch.tensor([float((idx // 2) % 2)], device=dev), torch.tensor([idx % C], device=dev), torch.tensor([idx % 2], device=dev))
 
 
@@ -273,6 +276,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bag-dtype", choices=["fp32", "fp16"], default="fp32",
+                    help="fp16: feature bags stored in half precision (toad_mil_step_x16_f32: two MFMA terms in the first layer, no abs-max pass); "
+                         "reported under its own metric name, BASELINE's configurations are fp32")
     ap.add_argument("--patches", type=int, default=0, help="patches per slide (default: 100,000; config 3: 10,000; config 4: 50,000)")
     ap.add_argument("--slides-per-rank", type=int, default=1)
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4], help="BASELINE.json config (0 = the headline step)")
@@ -283,6 +289,8 @@ def main():
     ap.add_argument("--single-device", action="store_true",
                     help="plumbing test only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     args = ap.parse_args()
+    global BAG_DTYPE
+    BAG_DTYPE = torch.float16 if args.bag_dtype == "fp16" else torch.float32
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -396,11 +404,13 @@ def main():
                   4: "slides/sec fwd+bwd, 64 slides x 50k patches per step, slide-sharded DP (BASELINE config 4)"}[args.config]
         if args.config == 0 and n != 100_000:
             metric = f"slides/sec fwd+bwd, {n}-patch x 1024-d bags"
+        if args.bag_dtype == "fp16":
+            metric += " STORED AS fp16 (not a BASELINE configuration)"
         out = {
             "metric": metric,
             "value": round(value, 3), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.bag_dtype == "fp32" else "f32 (bag stored as f16)", "data": "synthetic",
             "config": {"workload": f"TOAD_fc_mtl_concat(big, n_classes=18) fwd + 0.75/0.25 CE + bwd + Adam on "
                                    f"{len(slides[0])} x {n}-patch x 1024-d N(0,1) bag(s) per GPU per step, bags resident in HBM"
                                    + (f"; 64 slides per optimiser step dealt round robin over {world} rank(s)" if args.config == 4 else ""),

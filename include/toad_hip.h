@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOAD_ABI_VERSION 7
+#define TOAD_ABI_VERSION 8
 
 enum { TOAD_OK = 0, TOAD_EINVAL = -1, TOAD_ESHAPE = -2, TOAD_EWORKSPACE = -3, TOAD_EALIGN = -4 };
 enum { TOAD_ACT_NONE = 0, TOAD_ACT_RELU = 1 };
@@ -319,6 +319,29 @@ int toad_mil_step_f32(const float *const *params, float *const *grads, float bet
                       float drop_p, uint64_t seed, const float *x_amax,
                       float *loss_out, float *logits_out, float *site_logits_out,
                       void *ws, size_t ws_bytes, void **events, void *stream);
+
+/* ---- fp16 feature bags (ABI 8) -------------------------------------------------------------------------------------------
+ * The same three calls for a bag stored as fp16, X16 [N,1024] halves (16-byte aligned): the reference's data path upcasts whatever the
+ * .pt file holds when it reaches nn.Linear (datasets/dataset_mtl_concat.py:358-373 -> models/model_toad.py:91); feature stores kept in
+ * fp16 halve the PCIe / disk traffic that bounds streaming training. An fp16 element is exactly a first piece of
+ * the fp16 two-piece arithmetic (h = x, m = 0, scale 1), so the first Linear and its weight gradient run with TWO MFMA terms per
+ * product instead of three and read half the bytes; the results equal those of the fp32 calls on the up-cast bag (same products,
+ * same accumulation order). No abs-max array of X is needed; dX is not available (the bag is data, not a parameter).
+ * Needs the fp16 two-piece kernels for both products (toad_mil_x16_ok(N): 64 <= N, N * 4096 < 2^32); TOAD_ESHAPE otherwise. */
+int toad_mil_x16_ok(int64_t N);
+int toad_mil_fwd_x16_f32(const float *const *params, const void *X16, const float *sex, int64_t N, int C, int D,
+                         float drop_p, uint64_t seed, int attention_only,
+                         void *arena, size_t arena_bytes, void *scratch, size_t scratch_bytes, void *stream);
+int toad_mil_bwd_x16_f32(const float *const *params, float *const *grads, float beta, const void *X16, int64_t N, int C, int D,
+                         float drop_p, uint64_t seed, const void *arena, size_t arena_bytes,
+                         const float *dlogits, const float *dsite, const float *dA_ext, const float *dMcat_ext,
+                         float *dsex, void *scratch, size_t scratch_bytes, void *stream);
+int toad_mil_step_x16_f32(const float *const *params, float *const *grads, float beta, const void *X16,
+                          const float *sex, const int64_t *label, const int64_t *site,
+                          float w_cls, float w_site, int64_t N, int C, int D,
+                          float drop_p, uint64_t seed,
+                          float *loss_out, float *logits_out, float *site_logits_out,
+                          void *ws, size_t ws_bytes, void **events, void *stream);
 
 #ifdef __cplusplus
 }

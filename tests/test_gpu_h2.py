@@ -267,3 +267,65 @@ def test_one_bit_relu_image_gives_the_fp32_mask_result(cuda, m):
     r = ops.linear_dgrad(dy, w2t, relu_src=y, mask_scale=4.0 / 3.0)
     assert torch.equal(a, r)
     assert (a == 0).float().mean().item() > 0.5                                                   # the mask really masks
+
+
+# ---- fp16 feature bags (toad_mil_*_x16_f32) ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1, 255, 777, 2049, 20000])
+def test_fp16_bag_equals_the_upcast_bag(cuda, n):
+    """A bag stored as fp16 goes through the two-term kernels (first Linear: A16, its weight gradient: B16); an fp16 element is
+    exactly a first piece with m = 0, so every product and the accumulation order are those of the fp32 call on the up-cast bag:
+    outputs and all 14 gradients agree to round-off of the operand SCALING only (power-of-two scales: expected bitwise; the bound
+    below is 1e-6 of each tensor's magnitude to stay independent of that argument). Also: drop-in forward/backward, attention_only,
+    the fused step, and the errors (gradient w.r.t. an fp16 bag)."""
+    from toad_amd import TOAD_fc_mtl_concat, ops
+    from toad_amd.dp import hip_slide_grad
+    torch.manual_seed(5)
+    c = 18
+    model = TOAD_fc_mtl_concat(n_classes=c); model.relocate(); model.train()
+    g = torch.Generator().manual_seed(40 + n)
+    x16 = (torch.randn(n, 1024, generator=g) * 0.7).half().cuda()
+    x32 = x16.float()
+    sex = torch.tensor([1.0]).cuda(); label = torch.tensor([3]).cuda(); site = torch.tensor([1]).cuda()
+    loss_fn = torch.nn.CrossEntropyLoss()
+
+    def run(x):
+        model.zero_grad(set_to_none=True)
+        r = model(x, sex, return_features=True)
+        loss = loss_fn(r["logits"], label) * 0.75 + loss_fn(r["site_logits"], site) * 0.25
+        loss.backward()
+        return r, {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    r32, g32 = run(x32)
+    r16, g16 = run(x16)
+    for k in ("logits", "site_logits", "Y_prob", "site_prob", "features", "A"):
+        tol = 1e-6 * max(r32[k].abs().max().item(), 1e-6)
+        assert (r16[k] - r32[k]).abs().max().item() <= tol, k
+    assert torch.equal(r16["Y_hat"], r32["Y_hat"])
+    for k in g32:
+        tol = 1e-6 * max(g32[k].abs().max().item(), 1e-12)
+        assert (g16[k] - g32[k]).abs().max().item() <= tol, (k, (g16[k] - g32[k]).abs().max().item(), g32[k].abs().max().item())
+    with torch.no_grad():
+        a16, a32 = model(x16, sex, attention_only=True), model(x32, sex, attention_only=True)
+    assert (a16 - a32).abs().max().item() <= 1e-6 * max(a32.abs().max().item(), 1e-6)
+    # fused step
+    w = {k: v.detach() for k, v in model._weights().items()}
+    gr16 = {k: torch.zeros_like(v) for k, v in w.items()}
+    gr32 = {k: torch.zeros_like(v) for k, v in w.items()}
+    l16 = hip_slide_grad(model, gr16, (x16, sex, label, site), beta=0.0)
+    l32 = hip_slide_grad(model, gr32, (x32, sex, label, site), beta=0.0)
+    assert (l16 - l32).abs().max().item() <= 1e-6 * max(l32.abs().max().item(), 1.0)
+    for k in ops.STEP_SLOTS:
+        assert (gr16[k] - gr32[k]).abs().max().item() <= 1e-6 * max(gr32[k].abs().max().item(), 1e-12), k
+    # a bag that requires grad is up-cast (the fp16 kernels have no dX); bf16 is up-cast as well
+    xr = x16.clone().requires_grad_(True)
+    r = model(xr, sex)
+    (r["logits"].sum()).backward()
+    assert xr.grad is not None and xr.grad.dtype == torch.float16
+    rb = model(x16.bfloat16(), sex)
+    assert rb["logits"].dtype == torch.float32
+    if ops.x16_ok(n):
+        with pytest.raises(ValueError):
+            arena = ops.mil_fwd(w, x16, sex)
+            ops.mil_bwd(w, gr16, 0.0, x16, arena, torch.zeros(1, c).cuda(), torch.zeros(1, 2).cuda(), need_dx=True)
+    assert ops.x16_ok(n) == (n >= 64)                 # below 64 patches the bag is up-cast (the small wgrad kernel is fp32-only)

@@ -98,12 +98,12 @@ int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax,
 int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C,
                  int64_t ldc, int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
                  const float *mask_src, const unsigned long long *mask_bits, H2Pool pool, float *slabs, float *y_amax,
-                 unsigned long long *bits_out, hipStream_t st, const char *what);
+                 unsigned long long *bits_out, hipStream_t st, const char *what, bool a_half = false);
 int launch_pool_bwd(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *A_raw, const float *stats,
                     const float *M, const float *dM, const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH, float *dWc, float *dbc,
                     float beta, float *dp_amax, bool zero_amax, void *ws, size_t ws_bytes, int64_t N, int L, int D, int T, float drop_p,
                     uint64_t seed_a, uint64_t seed_b, hipStream_t st);
 int launch_wgrad(const float *dY, const float *dy_amax, const float *X, const float *x_amax, float *dW, float *db, int64_t M,
-                 int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what);
+                 int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what, bool x_half = false);
 
 }  // namespace toad

@@ -111,7 +111,9 @@ static int h2_enabled() {
         TOAD_H2_ATTR(true, false, 0); TOAD_H2_ATTR(true, false, 1); TOAD_H2_ATTR(true, false, 2);
         TOAD_H2_ATTR(false, true, 0); TOAD_H2_ATTR(false, true, 1);
 #undef TOAD_H2_ATTR
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_h2_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN2_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_h2_big_kernel<false, false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H2_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_h2_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TN2_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_h2_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TN2_SMEM);
     }
     return v;
 }
@@ -153,8 +155,29 @@ int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax,
 int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C,
                         int64_t ldc, int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
                         const float *mask_src, const unsigned long long *mask_bits, H2Pool pool, float *slabs, float *y_amax,
-                        unsigned long long *bits_out, hipStream_t st, const char *what) {
+                        unsigned long long *bits_out, hipStream_t st, const char *what, bool a_half) {
     const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
+    if (a_half) {          // A is fp16 [M, lda halves]: plain forward only (no addend / mask / pooling variants are instantiated)
+        if (addend || mask_src || mask_bits || pool.T > 0) { set_error("%s: the fp16-operand kernel has no addend / mask / pooling epilogue", what); return TOAD_EINVAL; }
+        hipLaunchKernelGGL((gemm_nt_h2_big_kernel<false, false, 0, true>), dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, (const float *)nullptr, planes,
+                           binv, C, ldc, (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, 0, slabs, y_amax, bits_out, tiles_m, tiles_n);
+        int rc16 = check_launch(what);
+        if (rc16) return rc16;
+        int max_rem16 = 0, rem_all16 = 0;
+        for (int x = 0; x < kNumXCD; ++x) { const NtPlan pl = nt_plan(x, tiles_m, tiles_n, (int)(K / BK)); if (pl.g > 1) { rem_all16 += pl.rem; if (pl.rem > max_rem16) max_rem16 = pl.rem; } }
+        if (max_rem16 > 0) {   // the fix-up takes the A scale from a_amax: fp16 operands carry scale 1 -> NULL selects exponent 0
+            const H2Pool np{nullptr, nullptr, nullptr, 0};
+            if (rem_all16 > 8)
+                hipLaunchKernelGGL(nt_fixup_h2_kernel<4>, dim3(16, max_rem16, kNumXCD), dim3(256), 0, st, (const float *)slabs, (const float *)nullptr, binv, C, ldc,
+                                   (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, np.a_raw, np.stats, np.dM, 0, y_amax, tiles_m, tiles_n);
+            else
+                hipLaunchKernelGGL(nt_fixup_h2_kernel<1>, dim3(64, max_rem16, kNumXCD), dim3(256), 0, st, (const float *)slabs, (const float *)nullptr, binv, C, ldc,
+                                   (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, np.a_raw, np.stats, np.dM, 0, y_amax, tiles_m, tiles_n);
+            rc16 = check_launch(what);
+        }
+        return rc16;
+    }
     if (pool.T > 0 && addend) { set_error("%s: an addend buffer and the recomputed pooling addend are mutually exclusive", what); return TOAD_EINVAL; }
     // whole tiles read the one-bit ReLU image when the caller has it (mask_bits), the fix-up kernel always reads the fp32 mask_src
     const float *msrc = mask_bits ? reinterpret_cast<const float *>(mask_bits) : mask_src;
@@ -348,6 +371,9 @@ extern "C" size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 extern "C" int toad_linear_h2_ok(int64_t M, int64_t N, int64_t K) { return h2_nt_ok(M, N, K, K, N) ? 1 : 0; }
+static bool tn_big_ok(int64_t M, int64_t N, int64_t K);
+// fp16 bags: both the first Linear (NT, A = bag) and its weight gradient (TN, B = bag) must take the fp16 two-piece kernels
+extern "C" int toad_mil_x16_ok(int64_t N) { return (h2_nt_ok(N, 512, 1024, 1024, 512) && tn_big_ok(N, 512, 1024)) ? 1 : 0; }
 extern "C" size_t toad_relu_bits_bytes(int64_t M, int64_t N) {
     if (M <= 0 || N <= 0) return 0;
     return (size_t)((M + PB - 1) / PB) * (size_t)((N + PB - 1) / PB) * 8 * 2 * 64 * sizeof(unsigned long long);   // 8 KB per 256 x 256 tile
@@ -484,7 +510,8 @@ extern "C" size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K) {
 
 // dW = beta*dW + dY^T X (+ db). dy_amax / x_amax: abs-max arrays of the operands (NULL -> measured here).
 int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, const float *x_amax, float *dW, float *db, int64_t M,
-                        int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what) {
+                        int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what, bool x_half) {
+    if (x_half && !(tn_big_ok(M, N, K) && h2_enabled())) { set_error("%s: an fp16 input operand needs the h2 wgrad kernel", what); return TOAD_ESHAPE; }
     float *slab = (float *)ws;
     int nsplit;
     int rc;
@@ -506,9 +533,14 @@ int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, co
             scales = slab + (size_t)nsplit * (size_t)(N * K + N);
             float *amax_ws = scales + 16;
             if (!dy_amax) { if ((rc = launch_absmax(dY, N, M, N, amax_ws, true, st, what))) return rc; dy_amax = amax_ws; }
-            if (!x_amax) { float *a2 = amax_ws + h2_nblk(M) + 16; if ((rc = launch_absmax(X, K, M, K, a2, true, st, what))) return rc; x_amax = a2; }
-            hipLaunchKernelGGL(gemm_tn_h2_big_kernel, dim3(PB_GRID), dim3(512), TN2_SMEM, st, dY, N, dy_amax, X, K, x_amax, slab, cs, scales,
-                               (int)M, (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
+            if (x_half) {
+                hipLaunchKernelGGL(gemm_tn_h2_big_kernel<true>, dim3(PB_GRID), dim3(512), TN2_SMEM, st, dY, N, dy_amax, X, K, (const float *)nullptr, slab, cs,
+                                   scales, (int)M, (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
+            } else {
+                if (!x_amax) { float *a2 = amax_ws + h2_nblk(M) + 16; if ((rc = launch_absmax(X, K, M, K, a2, true, st, what))) return rc; x_amax = a2; }
+                hipLaunchKernelGGL(gemm_tn_h2_big_kernel<false>, dim3(PB_GRID), dim3(512), TN2_SMEM, st, dY, N, dy_amax, X, K, x_amax, slab, cs, scales,
+                                   (int)M, (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
+            }
         } else if (tn_split)
             hipLaunchKernelGGL(gemm_tn_split_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, X, K, slab, cs, (int)M,
                                (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);

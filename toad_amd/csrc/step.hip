@@ -146,11 +146,12 @@ static DropSeeds drop_seeds(float drop_p, uint64_t seed) {          // must matc
 // forward up to the pooled features: trunk, stacked attention GEMM, fused gated pool. `ev` records bench events (or nothing).
 template <typename Ev>
 static int forward_body(const MilShape &s, const Params &p, const float *X, const float *x_amax, float drop_p, uint64_t seed,
-                        bool attention_only, const Fwd &f, const Scratch &w, hipStream_t st, Ev ev, const char *what) {
+                        bool attention_only, const Fwd &f, const Scratch &w, hipStream_t st, Ev ev, const char *what, bool x_half) {
     const int64_t N = s.N;
     const int D2 = 2 * s.D;
     const DropSeeds ds = drop_seeds(drop_p, seed);
     const bool h2 = h2_nt_ok(N, kL, kL0, kL0, kL);
+    if (x_half && !h2) { set_error("%s: an fp16 bag needs the fp16 two-piece kernels (N * 1024 * 4 < 2^32, TOAD_GEMM_H2 != 0)", what); return TOAD_ESHAPE; }
     const EpiScalars relu1{1, 1.f, make_drop(drop_p, ds.s1)}, relu2{1, 1.f, make_drop(drop_p, ds.s2)}, lin{0, 1.f, make_drop(0.f, 0)};
     const H2Pool nopool{nullptr, nullptr, nullptr, 0};
     if (h2) {
@@ -160,9 +161,11 @@ static int forward_body(const MilShape &s, const Params &p, const float *X, cons
         // one launch splits the three forward weight operands AND zeroes the three adjacent abs-max arrays (x, h1, h): no memsets
         const int nz = (int)(((char *)f.amax_h - (char *)f.amax_x) / sizeof(float) + toad_amax_floats(N));
         TOAD_TRY(launch_split_h2(ops, 3, f.amax_x, nz, st, what));
-        if (x_amax) (void)hipMemcpyAsync(f.amax_x, x_amax, toad_amax_floats(N) * sizeof(float), hipMemcpyDeviceToDevice, st);
+        // an fp16 bag needs no abs-max array: its elements are first pieces with scale 1 (gemm_nt_h2_big_kernel, A16)
+        if (x_half) {}
+        else if (x_amax) (void)hipMemcpyAsync(f.amax_x, x_amax, toad_amax_floats(N) * sizeof(float), hipMemcpyDeviceToDevice, st);
         else TOAD_TRY(launch_absmax(X, kL0, N, kL0, f.amax_x, false, st, what));
-        ev(2); TOAD_TRY(launch_nt_h2(X, kL0, f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h1, f.bits_h1, st, what)); ev(3);
+        ev(2); TOAD_TRY(launch_nt_h2(X, kL0, f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h1, f.bits_h1, st, what, x_half)); ev(3);
         ev(4); TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h, f.bits_h, st, what)); ev(5);
         ev(6); TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nullptr, nopool, w.slabs, nullptr, nullptr, st, what)); ev(7);
     } else {       // shapes beyond the persistent kernels' 32-bit offsets (> 1 M patches): the per-op entry points pick their kernels
@@ -181,11 +184,13 @@ static int forward_body(const MilShape &s, const Params &p, const float *X, cons
 // backward from dM (gradient of the pooled features) down to the trunk weights (and dX)
 template <typename Ev>
 static int backward_body(const MilShape &s, const Params &p, float *const *grads, float beta, const float *X, float drop_p, uint64_t seed,
-                         const Fwd &f, const float *dM, const float *dA_ext, float *dX, const Scratch &w, hipStream_t st, Ev ev, const char *what) {
+                         const Fwd &f, const float *dM, const float *dA_ext, float *dX, const Scratch &w, hipStream_t st, Ev ev, const char *what,
+                         bool x_half) {
     const int64_t N = s.N;
     const int D2 = 2 * s.D;
     const DropSeeds ds = drop_seeds(drop_p, seed);
     const bool h2 = h2_nt_ok(N, kL, kL0, kL0, kL);
+    if (x_half && !h2) { set_error("%s: an fp16 bag needs the fp16 two-piece kernels", what); return TOAD_ESHAPE; }
     const EpiScalars msk{0, ds.mscale, make_drop(0.f, 0)}, plain{0, 1.f, make_drop(0.f, 0)};
     const H2Pool nopool{nullptr, nullptr, nullptr, 0};
     if (h2) {
@@ -205,7 +210,7 @@ static int backward_body(const MilShape &s, const Params &p, float *const *grads
         ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws, st, what)); ev(13);
         ev(14); TOAD_TRY(launch_nt_h2(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, f.bits_h1, nopool,
                                       w.slabs, w.amax_dZ1, nullptr, st, what)); ev(15);
-        ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, X, f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws, st, what)); ev(17);
+        ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, X, f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws, st, what, x_half)); ev(17);
         if (dX) TOAD_TRY(launch_nt_h2(w.dZ1, kL, w.amax_dZ1, w.planes[W_1T], w.binv[W_1T], dX, kL0, N, kL0, kL, nullptr, plain, nullptr, nullptr, nullptr, nopool,
                                       w.slabs, nullptr, nullptr, st, what));
         return TOAD_OK;
@@ -269,10 +274,9 @@ static char *align_base(void *p, int64_t N) {
     return reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(p) + a - 1) & ~(a - 1));
 }
 
-extern "C" int toad_mil_fwd_f32(const float *const *params, const float *X, const float *sex, int64_t N, int C, int D, float drop_p,
-                                 uint64_t seed, const float *x_amax, int attention_only, void *arena, size_t arena_bytes,
-                                 void *scratch, size_t scratch_bytes, void *stream) {
-    const char *what = "toad_mil_fwd_f32";
+static int mil_fwd_impl(const float *const *params, const float *X, const float *sex, int64_t N, int C, int D, float drop_p,
+                        uint64_t seed, const float *x_amax, int attention_only, void *arena, size_t arena_bytes,
+                        void *scratch, size_t scratch_bytes, void *stream, bool x_half, const char *what) {
     const MilShape s{N, C, D};
     if (!params || !X || !arena || !scratch || (!attention_only && !sex)) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (!shape_ok(s)) { set_error("%s: unsupported shape N=%lld C=%d D=%d", what, (long long)N, C, D); return TOAD_ESHAPE; }
@@ -287,16 +291,28 @@ extern "C" int toad_mil_fwd_f32(const float *const *params, const float *X, cons
     if (!load_params(params, p, what)) return TOAD_EINVAL;
     const Fwd f = arena_view(s, ab);
     hipStream_t st = (hipStream_t)stream;
-    TOAD_TRY(forward_body(s, p, X, x_amax, drop_p, seed, attention_only != 0, f, w, st, NoEvents{}, what));
+    TOAD_TRY(forward_body(s, p, X, x_amax, drop_p, seed, attention_only != 0, f, w, st, NoEvents{}, what, x_half));
     if (attention_only) return TOAD_OK;
     return toad_heads_fwd_f32(f.M, sex, p.wcls, p.bcls, p.wsite, p.bsite, f.Mcat, f.logits, f.yprob, f.yhat, f.slog, f.sprob, f.shat, kL, C, st);
 }
 
-extern "C" int toad_mil_bwd_f32(const float *const *params, float *const *grads, float beta, const float *X, int64_t N, int C, int D,
-                                 float drop_p, uint64_t seed, const void *arena, size_t arena_bytes, const float *dlogits,
-                                 const float *dsite, const float *dA_ext, const float *dMcat_ext, float *dX, float *dsex,
+extern "C" int toad_mil_fwd_f32(const float *const *params, const float *X, const float *sex, int64_t N, int C, int D, float drop_p,
+                                 uint64_t seed, const float *x_amax, int attention_only, void *arena, size_t arena_bytes,
                                  void *scratch, size_t scratch_bytes, void *stream) {
-    const char *what = "toad_mil_bwd_f32";
+    return mil_fwd_impl(params, X, sex, N, C, D, drop_p, seed, x_amax, attention_only, arena, arena_bytes, scratch, scratch_bytes, stream, false,
+                        "toad_mil_fwd_f32");
+}
+extern "C" int toad_mil_fwd_x16_f32(const float *const *params, const void *X16, const float *sex, int64_t N, int C, int D, float drop_p,
+                                     uint64_t seed, int attention_only, void *arena, size_t arena_bytes, void *scratch, size_t scratch_bytes,
+                                     void *stream) {
+    return mil_fwd_impl(params, reinterpret_cast<const float *>(X16), sex, N, C, D, drop_p, seed, nullptr, attention_only, arena, arena_bytes, scratch,
+                        scratch_bytes, stream, true, "toad_mil_fwd_x16_f32");
+}
+
+static int mil_bwd_impl(const float *const *params, float *const *grads, float beta, const float *X, int64_t N, int C, int D,
+                        float drop_p, uint64_t seed, const void *arena, size_t arena_bytes, const float *dlogits,
+                        const float *dsite, const float *dA_ext, const float *dMcat_ext, float *dX, float *dsex,
+                        void *scratch, size_t scratch_bytes, void *stream, bool x_half, const char *what) {
     const MilShape s{N, C, D};
     if (!params || !grads || !X || !arena || !scratch || !dlogits || !dsite) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (!shape_ok(s)) { set_error("%s: unsupported shape N=%lld C=%d D=%d", what, (long long)N, C, D); return TOAD_ESHAPE; }
@@ -312,17 +328,31 @@ extern "C" int toad_mil_bwd_f32(const float *const *params, float *const *grads,
     const Fwd f = arena_view(s, ab);
     hipStream_t st = (hipStream_t)stream;
     TOAD_TRY(toad_heads_bwd_f32(f.Mcat, dlogits, dsite, p.wcls, p.wsite, dMcat_ext, grads[8], grads[9], grads[10], grads[11], w.dM, dsex, beta, kL, C, st));
-    return backward_body(s, p, grads, beta, X, drop_p, seed, f, w.dM, dA_ext, dX, w, st, NoEvents{}, what);
+    return backward_body(s, p, grads, beta, X, drop_p, seed, f, w.dM, dA_ext, dX, w, st, NoEvents{}, what, x_half);
+}
+
+extern "C" int toad_mil_bwd_f32(const float *const *params, float *const *grads, float beta, const float *X, int64_t N, int C, int D,
+                                 float drop_p, uint64_t seed, const void *arena, size_t arena_bytes, const float *dlogits,
+                                 const float *dsite, const float *dA_ext, const float *dMcat_ext, float *dX, float *dsex,
+                                 void *scratch, size_t scratch_bytes, void *stream) {
+    return mil_bwd_impl(params, grads, beta, X, N, C, D, drop_p, seed, arena, arena_bytes, dlogits, dsite, dA_ext, dMcat_ext, dX, dsex, scratch,
+                        scratch_bytes, stream, false, "toad_mil_bwd_f32");
+}
+extern "C" int toad_mil_bwd_x16_f32(const float *const *params, float *const *grads, float beta, const void *X16, int64_t N, int C, int D,
+                                     float drop_p, uint64_t seed, const void *arena, size_t arena_bytes, const float *dlogits,
+                                     const float *dsite, const float *dA_ext, const float *dMcat_ext, float *dsex,
+                                     void *scratch, size_t scratch_bytes, void *stream) {
+    return mil_bwd_impl(params, grads, beta, reinterpret_cast<const float *>(X16), N, C, D, drop_p, seed, arena, arena_bytes, dlogits, dsite, dA_ext,
+                        dMcat_ext, nullptr, dsex, scratch, scratch_bytes, stream, true, "toad_mil_bwd_x16_f32");
 }
 
 // events: NULL, or 18 hipEvent_t: [0,1] bracket the fused pool forward, [2+2i, 3+2i] bracket GEMM call i
 // (fwd1, fwd2, fwd_ab, wgrad_ab, dgrad_ab, wgrad_2, dgrad_2, wgrad_1) - for bench.py's roofline figures.
-extern "C" int toad_mil_step_f32(const float *const *params, float *const *grads, float beta, const float *X,
-                                  const float *sex, const int64_t *label, const int64_t *site, float w_cls,
-                                  float w_site, int64_t N, int C, int D, float drop_p, uint64_t seed, const float *x_amax,
-                                  float *loss_out, float *logits_out, float *site_logits_out, void *ws,
-                                  size_t ws_bytes, void **events, void *stream) {
-    const char *what = "toad_mil_step_f32";
+static int mil_step_impl(const float *const *params, float *const *grads, float beta, const float *X,
+                         const float *sex, const int64_t *label, const int64_t *site, float w_cls,
+                         float w_site, int64_t N, int C, int D, float drop_p, uint64_t seed, const float *x_amax,
+                         float *loss_out, float *logits_out, float *site_logits_out, void *ws,
+                         size_t ws_bytes, void **events, void *stream, bool x_half, const char *what) {
     const MilShape s{N, C, D};
     if (!params || !grads || !X || !sex || !label || !site || !loss_out || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (!shape_ok(s)) { set_error("%s: unsupported shape N=%lld C=%d D=%d", what, (long long)N, C, D); return TOAD_ESHAPE; }
@@ -339,11 +369,27 @@ extern "C" int toad_mil_step_f32(const float *const *params, float *const *grads
     const Scratch w = scratch_layout(s, sb);
     hipStream_t st = (hipStream_t)stream;
     const StreamEvents ev{events, st};
-    TOAD_TRY(forward_body(s, p, X, x_amax, drop_p, seed, false, f, w, st, ev, what));
+    TOAD_TRY(forward_body(s, p, X, x_amax, drop_p, seed, false, f, w, st, ev, what, x_half));
     // heads + weighted CE + heads backward: one single-workgroup launch
     TOAD_TRY(toad_heads_ce_fused_f32(f.M, sex, p.wcls, p.bcls, p.wsite, p.bsite, label, site, w_cls, w_site, f.Mcat, f.logits, f.yprob, f.yhat,
                                      f.slog, f.sprob, f.shat, loss_out, nullptr, nullptr, grads[8], grads[9], grads[10], grads[11], w.dM, beta, kL, C, st));
     if (logits_out) (void)hipMemcpyAsync(logits_out, f.logits, C * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (site_logits_out) (void)hipMemcpyAsync(site_logits_out, f.slog, 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
-    return backward_body(s, p, grads, beta, X, drop_p, seed, f, w.dM, nullptr, nullptr, w, st, ev, what);
+    return backward_body(s, p, grads, beta, X, drop_p, seed, f, w.dM, nullptr, nullptr, w, st, ev, what, x_half);
+}
+extern "C" int toad_mil_step_f32(const float *const *params, float *const *grads, float beta, const float *X,
+                                  const float *sex, const int64_t *label, const int64_t *site, float w_cls,
+                                  float w_site, int64_t N, int C, int D, float drop_p, uint64_t seed, const float *x_amax,
+                                  float *loss_out, float *logits_out, float *site_logits_out, void *ws,
+                                  size_t ws_bytes, void **events, void *stream) {
+    return mil_step_impl(params, grads, beta, X, sex, label, site, w_cls, w_site, N, C, D, drop_p, seed, x_amax, loss_out, logits_out,
+                         site_logits_out, ws, ws_bytes, events, stream, false, "toad_mil_step_f32");
+}
+extern "C" int toad_mil_step_x16_f32(const float *const *params, float *const *grads, float beta, const void *X16,
+                                      const float *sex, const int64_t *label, const int64_t *site, float w_cls,
+                                      float w_site, int64_t N, int C, int D, float drop_p, uint64_t seed,
+                                      float *loss_out, float *logits_out, float *site_logits_out, void *ws,
+                                      size_t ws_bytes, void **events, void *stream) {
+    return mil_step_impl(params, grads, beta, reinterpret_cast<const float *>(X16), sex, label, site, w_cls, w_site, N, C, D, drop_p, seed, nullptr,
+                         loss_out, logits_out, site_logits_out, ws, ws_bytes, events, stream, true, "toad_mil_step_x16_f32");
 }

@@ -50,6 +50,7 @@ def hip_slide_grad(model, grads: Dict[str, torch.Tensor], slide: Slide, beta: fl
     from . import ops
     from .model_toad import _draw_dropout
     bag, sex, label, site = slide
+    bag = model._bag_dtype(bag.contiguous())                  # fp32, or fp16 as stored (toad_mil_step_x16_f32)
     w = {k: v.detach() for k, v in model._weights().items()}
     drop_p, seed = _draw_dropout(model._dropout and model.training)
     if bag.shape[0] == 0:

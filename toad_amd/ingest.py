@@ -38,7 +38,10 @@ class BagPrefetcher:
     """Iterate ``(bag, label, site, sex)`` device tensors in record order with ``depth`` bags in flight."""
 
     def __init__(self, records: Sequence[Record], device: Union[str, torch.device], depth: int = 2, workers: int = 2,
-                 dtype: torch.dtype = torch.float32):
+                 dtype: Optional[torch.dtype] = torch.float32):
+        """``dtype``: what the consumer receives. ``torch.float32`` (default) up-casts fp16 / bf16 files on the device;
+        ``torch.float16`` hands fp16 bags to the model as they are (its first Linear and weight gradient then run the two-term
+        fp16 kernels, toad_mil_*_x16_f32: no up-cast pass, half the HBM reads of the bag); ``None`` keeps every file's own dtype."""
         self.records = list(records)
         self.device = torch.device(device)
         self.depth = max(1, int(depth))
@@ -66,10 +69,10 @@ class BagPrefetcher:
     def _stage_device(self, host):
         t, meta, sx = host
         if not self.on_gpu:
-            return (t.to(self.dtype), meta[0:1], meta[1:2], sx), None
+            return (t if self.dtype is None else t.to(self.dtype), meta[0:1], meta[1:2], sx), None
         with torch.cuda.stream(self.copy_stream):
             bag = t.to(self.device, non_blocking=True)
-            if bag.dtype != self.dtype:
+            if self.dtype is not None and bag.dtype != self.dtype:
                 bag = bag.to(self.dtype)                        # fp16/bf16 on disk: half the PCIe bytes, upcast here
             meta_d = meta.to(self.device, non_blocking=True)
             sx_d = sx.to(self.device, non_blocking=True)

@@ -228,12 +228,23 @@ class TOAD_fc_mtl_concat(nn.Module):
         self.to(device)
         self.flatten_parameters()
 
+    @staticmethod
+    def _bag_dtype(h: torch.Tensor) -> torch.Tensor:
+        """fp32 bags pass; fp16 bags (feature stores kept in half precision) go to the kernels as they are when the whole-slide
+        fp16 entry points take the shape (toad_mil_*_x16_f32: same results as the up-cast bag, two MFMA terms instead of three in the
+        first layer); everything else (bf16, fp64, empty or oversized fp16 bags) is up-cast to fp32 like nn.Linear's caller would."""
+        if h.dtype == torch.float32:
+            return h
+        if h.dtype == torch.float16 and h.dim() == 2 and h.shape[1] == 1024 and not h.requires_grad and ops.x16_ok(h.shape[0]):
+            return h
+        return h.float()
+
     def forward(self, h, sex, return_features=False, attention_only=False):
         _require_cuda(h, "h")
         drop_p, seed = _draw_dropout(self._dropout and self.training)
         w = self._weights()
         _require_cuda(w["w1"], "model parameters")
-        h = h.contiguous()
+        h = self._bag_dtype(h.contiguous())
         if attention_only:
             with torch.no_grad():
                 wd = {k: v.detach() for k, v in w.items()}
@@ -268,7 +279,7 @@ class TOAD_fc_mtl_concat(nn.Module):
         256-row block of the CONCATENATED operand, so the values agree with the one-slide path to fp32 round-off, not bitwise."""
         if self.training and self._dropout:
             raise RuntimeError("forward_many is an inference path: call model.eval() first (dropout would be skipped)")
-        bags = [b.contiguous() for b in bags]
+        bags = [b.contiguous() if b.dtype == torch.float32 else b.float().contiguous() for b in bags]   # (the per-op GEMMs of this path are fp32-only)
         if len(bags) != len(sexes):
             raise ValueError("forward_many: one sex entry per bag")
         if not bags:

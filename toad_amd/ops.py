@@ -131,6 +131,11 @@ def h2_ok(m: int, n: int, k: int) -> bool:
     return bool(_lib.load().toad_linear_h2_ok(int(m), int(n), int(k)))
 
 
+def x16_ok(n: int) -> bool:
+    """True when a [n, 1024] fp16 bag can go through the whole-slide fp16 entry points (toad_mil_*_x16_f32)."""
+    return bool(_lib.load().toad_mil_x16_ok(int(n)))
+
+
 def relu_bits_bytes(m: int, n: int) -> int:
     return int(_lib.load().toad_relu_bits_bytes(int(m), int(n)))
 
@@ -372,6 +377,15 @@ def _ptr_array(tensors):
     return arr
 
 
+def _chk_bag(bag: torch.Tensor) -> bool:
+    """The bag of a whole-slide call: fp32, or fp16 (features stored in half precision: toad_mil_*_x16_f32). -> is_half"""
+    if bag.dtype == torch.float16:
+        _chk(bag, "bag", dtype=torch.float16)
+        return True
+    _chk(bag, "bag")
+    return False
+
+
 def _step_dims(w, bag):
     c = w["wcls"].shape[0]
     d = w["wc"].shape[1]
@@ -385,7 +399,8 @@ def mil_step(w, grads, beta: float, bag, sex, label, site, w_cls: float = 0.75, 
     """forward + weighted CE + backward for one slide in ONE library call. ``w`` / ``grads`` map the STEP_SLOTS
     to tensors (grads = beta*grads + gradient). Returns (loss[3], logits [1,C] | None, site_logits [1,2] | None)."""
     import ctypes
-    _chk(bag, "bag"); _chk(sex, "sex"); _chk(label, "label", dtype=torch.int64); _chk(site, "site", dtype=torch.int64)
+    half = _chk_bag(bag)
+    _chk(sex, "sex"); _chk(label, "label", dtype=torch.int64); _chk(site, "site", dtype=torch.int64)
     _chk(x_amax, "x_amax", allow_none=True)
     ws_t = [w[k] for k in STEP_SLOTS]
     gs_t = [grads[k] for k in STEP_SLOTS]
@@ -406,9 +421,14 @@ def mil_step(w, grads, beta: float, bag, sex, label, site, w_cls: float = 0.75, 
         nev = 18 if _TIMING_LEVEL >= 2 else 2
         ev_objs = [_take_event() for _ in range(nev)]
         events = (ctypes.c_void_p * 18)(*([e.cuda_event for e in ev_objs] + [None] * (18 - nev)))
-    _lib.check(lib.toad_mil_step_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag), _p(sex), _p(label), _p(site),
-                                     float(w_cls), float(w_site), n, c, d, float(drop_p), int(seed), _p(x_amax), _p(loss), _p(logits),
-                                     _p(slog), _p(ws), ws.numel(), events, _stream()), "toad_mil_step_f32")
+    if half:
+        _lib.check(lib.toad_mil_step_x16_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag), _p(sex), _p(label), _p(site),
+                                             float(w_cls), float(w_site), n, c, d, float(drop_p), int(seed), _p(loss), _p(logits),
+                                             _p(slog), _p(ws), ws.numel(), events, _stream()), "toad_mil_step_x16_f32")
+    else:
+        _lib.check(lib.toad_mil_step_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag), _p(sex), _p(label), _p(site),
+                                         float(w_cls), float(w_site), n, c, d, float(drop_p), int(seed), _p(x_amax), _p(loss), _p(logits),
+                                         _p(slog), _p(ws), ws.numel(), events, _stream()), "toad_mil_step_f32")
     if ev_objs is not None:
         _TIMING.setdefault("pool_fwd", []).append((ev_objs[0], ev_objs[1]))
         if len(ev_objs) == 18:
@@ -447,7 +467,8 @@ class MilArena:
 def mil_fwd(w, bag, sex, drop_p: float = 0.0, seed: int = 0, attention_only: bool = False,
             x_amax: Optional[torch.Tensor] = None) -> MilArena:
     """models/model_toad.py:90-116 for one bag in ONE library call; returns the arena (outputs + what backward needs)."""
-    _chk(bag, "bag"); _chk(sex, "sex", allow_none=attention_only); _chk(x_amax, "x_amax", allow_none=True)
+    half = _chk_bag(bag)
+    _chk(sex, "sex", allow_none=attention_only); _chk(x_amax, "x_amax", allow_none=True)
     ws_t = [w[k] for k in STEP_SLOTS]
     for k, t in zip(STEP_SLOTS, ws_t):
         _chk(t, k)
@@ -456,16 +477,24 @@ def mil_fwd(w, bag, sex, drop_p: float = 0.0, seed: int = 0, attention_only: boo
     arena = MilArena(n, c, d, bag.device)
     scratch = _ws(lib.toad_mil_scratch_bytes(n, c, d), bag.device, "mil")
     with _timed("mil_fwd"):
-        _lib.check(lib.toad_mil_fwd_f32(_ptr_array(ws_t), _p(bag), _p(sex), n, c, d, float(drop_p), int(seed), _p(x_amax),
-                                        1 if attention_only else 0, _p(arena.buf), arena.buf.numel(), _p(scratch), scratch.numel(),
-                                        _stream()), "toad_mil_fwd_f32")
+        if half:
+            _lib.check(lib.toad_mil_fwd_x16_f32(_ptr_array(ws_t), _p(bag), _p(sex), n, c, d, float(drop_p), int(seed),
+                                                1 if attention_only else 0, _p(arena.buf), arena.buf.numel(), _p(scratch), scratch.numel(),
+                                                _stream()), "toad_mil_fwd_x16_f32")
+        else:
+            _lib.check(lib.toad_mil_fwd_f32(_ptr_array(ws_t), _p(bag), _p(sex), n, c, d, float(drop_p), int(seed), _p(x_amax),
+                                            1 if attention_only else 0, _p(arena.buf), arena.buf.numel(), _p(scratch), scratch.numel(),
+                                            _stream()), "toad_mil_fwd_f32")
     return arena
 
 
 def mil_bwd(w, grads, beta: float, bag, arena: MilArena, dlogits, dsite, da_ext=None, dmcat_ext=None, drop_p: float = 0.0,
             seed: int = 0, need_dx: bool = False, need_dsex: bool = False):
     """Backward of mil_fwd in ONE library call: grads[slot] = beta*grads[slot] + gradient. Returns (dX | None, dsex | None)."""
-    _chk(bag, "bag"); _chk(dlogits, "dlogits"); _chk(dsite, "dsite")
+    half = _chk_bag(bag)
+    if half and need_dx:
+        raise ValueError("mil_bwd: no gradient with respect to an fp16 bag (up-cast it to float32 if the bag itself is trained)")
+    _chk(dlogits, "dlogits"); _chk(dsite, "dsite")
     _chk(da_ext, "da_ext", allow_none=True); _chk(dmcat_ext, "dmcat_ext", allow_none=True)
     ws_t = [w[k] for k in STEP_SLOTS]
     gs_t = [grads[k] for k in STEP_SLOTS]
@@ -485,9 +514,14 @@ def mil_bwd(w, grads, beta: float, bag, arena: MilArena, dlogits, dsite, da_ext=
     scratch = _ws(lib.toad_mil_scratch_bytes(n, c, d), dev, "mil")
     buf = arena.buf
     with _timed("mil_bwd"):
-        _lib.check(lib.toad_mil_bwd_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag), n, c, d, float(drop_p), int(seed),
-                                        _p(buf), buf.numel(), _p(dlogits), _p(dsite), _p(da_ext), _p(dmcat_ext), _p(dx), _p(dsex),
-                                        _p(scratch), scratch.numel(), _stream()), "toad_mil_bwd_f32")
+        if half:
+            _lib.check(lib.toad_mil_bwd_x16_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag), n, c, d, float(drop_p), int(seed),
+                                                _p(buf), buf.numel(), _p(dlogits), _p(dsite), _p(da_ext), _p(dmcat_ext), _p(dsex),
+                                                _p(scratch), scratch.numel(), _stream()), "toad_mil_bwd_x16_f32")
+        else:
+            _lib.check(lib.toad_mil_bwd_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag), n, c, d, float(drop_p), int(seed),
+                                            _p(buf), buf.numel(), _p(dlogits), _p(dsite), _p(da_ext), _p(dmcat_ext), _p(dx), _p(dsex),
+                                            _p(scratch), scratch.numel(), _stream()), "toad_mil_bwd_f32")
     return dx, dsex
 
 

@@ -125,7 +125,7 @@ def train_loop(epoch: int, model, loader: Iterable, optimizer, n_classes: int, l
         if fused and data.shape[0] > 0:
             w = {k: v.detach() for k, v in model._weights().items()}
             drop_p, seed = _draw_dropout(model._dropout and model.training)
-            loss3, logits, slog = ops.mil_step(w, fg.views, 0.0, data.contiguous(), sex.reshape(1), label.reshape(1), site.reshape(1),
+            loss3, logits, slog = ops.mil_step(w, fg.views, 0.0, model._bag_dtype(data.contiguous()), sex.reshape(1), label.reshape(1), site.reshape(1),
                                                0.75, 0.25, drop_p, seed, want_logits=True)
             y_hat, s_hat = logits.argmax(1), slog.argmax(1)
             cls_logger.log(y_hat, label)
