@@ -127,3 +127,43 @@ def test_fused_train_loop_equals_the_reference_sequence(cuda, opt):
         get_optim(None, SimpleNamespace(opt="rmsprop", lr=1e-4, reg=0.0))
     with pytest.raises(ValueError):
         train_loop(0, TOAD_fc_mtl_concat(n_classes=c).cuda(), slides, None, c, loss_fn=torch.nn.CrossEntropyLoss(label_smoothing=0.1), fused=True)
+
+
+def test_grouping_plan_and_get_optim_cpu():
+    """Host logic that needs no GPU: the ragged grouping plan of forward_grouped (loader order preserved, groups cut at the row budget,
+    oversized slides alone, models without forward_many called slide by slide), get_optim's torch branch and error branch
+    (utils/utils.py:63-70), and train_loop's refusal to fuse for anything but the HIP module."""
+    from types import SimpleNamespace
+    from toad_amd.eval import forward_grouped
+    from toad_amd.optim import get_optim
+    from toad_amd.train import _fused_ok
+    lens = [300, 5000, 40, 40, 1200, 7, 900, 2600, 0, 10]
+    batches = [(torch.zeros(n, 4), torch.tensor([0]), torch.tensor([0]), torch.tensor([0.0])) for n in lens]
+    calls = []
+
+    class Spy:
+        def __call__(self, data, sex):
+            calls.append([int(data.shape[0])]); return {"n": int(data.shape[0])}
+
+        def forward_many(self, bags, sexes):
+            calls.append([int(b.shape[0]) for b in bags]); return [{"n": int(b.shape[0])} for b in bags]
+
+    got = [(int(b[0].shape[0]), r["n"]) for b, r in forward_grouped(Spy(), batches, 4096)]
+    assert got == [(n, n) for n in lens]
+    assert calls == [[300], [5000], [40, 40, 1200, 7, 900], [2600], [0], [10]]
+    calls.clear()
+    assert [r["n"] for _, r in forward_grouped(Spy(), batches, 0)] == lens and calls == [[n] for n in lens]
+
+    class Plain:                                            # a model without forward_many: one call per slide
+        def __call__(self, data, sex):
+            return {"n": int(data.shape[0])}
+
+    assert [r["n"] for _, r in forward_grouped(Plain(), batches, 4096)] == lens
+    lin = torch.nn.Linear(3, 2)
+    o = get_optim(lin, SimpleNamespace(opt="adam", lr=1e-3, reg=1e-4), flat=False)
+    assert isinstance(o, torch.optim.Adam) and o.defaults["lr"] == 1e-3 and o.defaults["weight_decay"] == 1e-4
+    o = get_optim(lin, SimpleNamespace(opt="sgd", lr=1e-2, reg=0.0), flat=False)
+    assert isinstance(o, torch.optim.SGD) and o.defaults["momentum"] == 0.9
+    with pytest.raises(NotImplementedError):
+        get_optim(lin, SimpleNamespace(opt="adagrad", lr=1e-2, reg=0.0))
+    assert not _fused_ok(lin, o, None)
