@@ -93,7 +93,8 @@ bool h2_nt_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc);
 size_t h2_planes_bytes(int64_t N, int64_t K);
 size_t h2_binv_bytes(int64_t N);
 size_t h2_slab_bytes();
-int launch_split_h2(const H2Operand *ops, int n, float *zero, int zero_n, hipStream_t st, const char *what);   // also zeroes zero[0..zero_n)
+int launch_split_h2(const H2Operand *ops, int n, float *zero, int zero_n, hipStream_t st, const char *what, float *zero2 = nullptr,
+                    int zero2_n = 0);                                                                            // also zeroes zero[0..zero_n) and zero2[0..zero2_n)
 int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax, bool zero, hipStream_t st, const char *what);
 int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C,
                  int64_t ldc, int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,

@@ -126,11 +126,13 @@ size_t h2_slab_bytes() { return (size_t)PB_GRID * PB * PB * sizeof(float); }
 size_t h2_binv_bytes(int64_t N) { return (size_t)((N + PB - 1) / PB) * PB * sizeof(float); }
 
 // split up to 6 weight operands into planes + inverse row scales with ONE launch
-int launch_split_h2(const H2Operand *ops, int n, float *zero, int zero_n, hipStream_t st, const char *what) {
+int launch_split_h2(const H2Operand *ops, int n, float *zero, int zero_n, hipStream_t st, const char *what, float *zero2, int zero2_n) {
     H2SplitBatch b;
     b.n = n;
     b.zero = zero;
     b.zero_n = zero ? zero_n : 0;
+    b.zero2 = zero2;
+    b.zero2_n = zero2 ? zero2_n : 0;
     int waves = 0;
     for (int i = 0; i < 6; ++i) {
         if (i < n) {

@@ -146,7 +146,8 @@ static DropSeeds drop_seeds(float drop_p, uint64_t seed) {          // must matc
 // forward up to the pooled features: trunk, stacked attention GEMM, fused gated pool. `ev` records bench events (or nothing).
 template <typename Ev>
 static int forward_body(const MilShape &s, const Params &p, const float *X, const float *x_amax, float drop_p, uint64_t seed,
-                        bool attention_only, const Fwd &f, const Scratch &w, hipStream_t st, Ev ev, const char *what, bool x_half) {
+                        bool attention_only, const Fwd &f, const Scratch &w, hipStream_t st, Ev ev, const char *what, bool x_half,
+                        bool with_backward_operands = false) {
     const int64_t N = s.N;
     const int D2 = 2 * s.D;
     const DropSeeds ds = drop_seeds(drop_p, seed);
@@ -160,7 +161,16 @@ static int forward_body(const MilShape &s, const Params &p, const float *X, cons
                                   {p.wab, kL, 1, D2, kL, w.planes[W_AB], w.binv[W_AB]}};
         // one launch splits the three forward weight operands AND zeroes the three adjacent abs-max arrays (x, h1, h): no memsets
         const int nz = (int)(((char *)f.amax_h - (char *)f.amax_x) / sizeof(float) + toad_amax_floats(N));
-        TOAD_TRY(launch_split_h2(ops, 3, f.amax_x, nz, st, what));
+        if (with_backward_operands) {
+            // the fused step knows its backward follows with the same weights: the two dgrad operands (transposed in place) and the
+            // backward's abs-max arrays go into the same launch (one launch less per slide; backward_body is told `presplit`)
+            const H2Operand ops5[5] = {ops[0], ops[1], ops[2], {p.wab, 1, kL, kL, D2, w.planes[W_ABT], w.binv[W_ABT]},
+                                       {p.w2, 1, kL, kL, kL, w.planes[W_2T], w.binv[W_2T]}};
+            const int nzb = (int)(((char *)w.amax_dZ1 - (char *)w.amax_dP) / sizeof(float) + toad_amax_floats(N));
+            TOAD_TRY(launch_split_h2(ops5, 5, f.amax_x, nz, st, what, w.amax_dP, nzb));
+        } else {
+            TOAD_TRY(launch_split_h2(ops, 3, f.amax_x, nz, st, what));
+        }
         // an fp16 bag needs no abs-max array: its elements are first pieces with scale 1 (gemm_nt_h2_big_kernel, A16)
         if (x_half) {}
         else if (x_amax) (void)hipMemcpyAsync(f.amax_x, x_amax, toad_amax_floats(N) * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -185,7 +195,7 @@ static int forward_body(const MilShape &s, const Params &p, const float *X, cons
 template <typename Ev>
 static int backward_body(const MilShape &s, const Params &p, float *const *grads, float beta, const float *X, float drop_p, uint64_t seed,
                          const Fwd &f, const float *dM, const float *dA_ext, float *dX, const Scratch &w, hipStream_t st, Ev ev, const char *what,
-                         bool x_half) {
+                         bool x_half, bool presplit = false) {
     const int64_t N = s.N;
     const int D2 = 2 * s.D;
     const DropSeeds ds = drop_seeds(drop_p, seed);
@@ -200,7 +210,7 @@ static int backward_body(const MilShape &s, const Params &p, float *const *grads
                                   {p.w2, 1, kL, kL, kL, w.planes[W_2T], w.binv[W_2T]},
                                   {p.w1, 1, kL0, kL0, kL, w.planes[W_1T], w.binv[W_1T]}};
         const int nz = (int)(((char *)w.amax_dZ1 - (char *)w.amax_dP) / sizeof(float) + toad_amax_floats(N));
-        TOAD_TRY(launch_split_h2(ops, dX ? 3 : 2, w.amax_dP, nz, st, what));
+        if (!(presplit && !dX)) TOAD_TRY(launch_split_h2(ops, dX ? 3 : 2, w.amax_dP, nz, st, what));
         TOAD_TRY(launch_pool_bwd(f.P, f.P + s.D, D2, f.H, p.wc, f.A_raw, f.stats, f.M, dM, dA_ext, w.dP, w.dP + s.D, D2, nullptr,
                                  grads[6], grads[7], beta, w.amax_dP, false, w.poolb_ws, w.poolb_ws_bytes, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st));
         ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what)); ev(9);
@@ -369,13 +379,14 @@ static int mil_step_impl(const float *const *params, float *const *grads, float 
     const Scratch w = scratch_layout(s, sb);
     hipStream_t st = (hipStream_t)stream;
     const StreamEvents ev{events, st};
-    TOAD_TRY(forward_body(s, p, X, x_amax, drop_p, seed, false, f, w, st, ev, what, x_half));
+    const bool presplit = h2_nt_ok(N, kL, kL0, kL0, kL);
+    TOAD_TRY(forward_body(s, p, X, x_amax, drop_p, seed, false, f, w, st, ev, what, x_half, presplit));
     // heads + weighted CE + heads backward: one single-workgroup launch
     TOAD_TRY(toad_heads_ce_fused_f32(f.M, sex, p.wcls, p.bcls, p.wsite, p.bsite, label, site, w_cls, w_site, f.Mcat, f.logits, f.yprob, f.yhat,
                                      f.slog, f.sprob, f.shat, loss_out, nullptr, nullptr, grads[8], grads[9], grads[10], grads[11], w.dM, beta, kL, C, st));
     if (logits_out) (void)hipMemcpyAsync(logits_out, f.logits, C * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (site_logits_out) (void)hipMemcpyAsync(site_logits_out, f.slog, 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
-    return backward_body(s, p, grads, beta, X, drop_p, seed, f, w.dM, nullptr, nullptr, w, st, ev, what, x_half);
+    return backward_body(s, p, grads, beta, X, drop_p, seed, f, w.dM, nullptr, nullptr, w, st, ev, what, x_half, presplit);
 }
 extern "C" int toad_mil_step_f32(const float *const *params, float *const *grads, float beta, const float *X,
                                   const float *sex, const int64_t *label, const int64_t *site, float w_cls,
