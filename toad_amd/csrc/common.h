@@ -104,7 +104,12 @@ int launch_pool_bwd(const float *Pa, const float *Pb, int64_t ldp, const float *
                     const float *M, const float *dM, const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH, float *dWc, float *dbc,
                     float beta, float *dp_amax, bool zero_amax, void *ws, size_t ws_bytes, int64_t N, int L, int D, int T, float drop_p,
                     uint64_t seed_a, uint64_t seed_b, hipStream_t st);
+struct WgradDeferred;
 int launch_wgrad(const float *dY, const float *dy_amax, const float *X, const float *x_amax, float *dW, float *db, int64_t M,
-                 int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what, bool x_half = false);
+                 int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what, bool x_half = false,
+                 struct WgradDeferred *defer = nullptr);
+// a weight gradient whose slab reduction was deferred (launch_wgrad with `defer`): up to three are reduced by ONE launch_wgrad_reduce
+struct WgradDeferred { const float *slab; float *out; int64_t n; const float *slab2; float *out2; int64_t n2; int nsplit; float beta; const float *scales; };
+int launch_wgrad_reduce(const WgradDeferred *d, int count, hipStream_t st, const char *what);
 
 }  // namespace toad

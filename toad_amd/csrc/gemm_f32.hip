@@ -512,7 +512,7 @@ extern "C" size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K) {
 
 // dW = beta*dW + dY^T X (+ db). dy_amax / x_amax: abs-max arrays of the operands (NULL -> measured here).
 int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, const float *x_amax, float *dW, float *db, int64_t M,
-                        int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what, bool x_half) {
+                        int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what, bool x_half, WgradDeferred *defer) {
     if (x_half && !(tn_big_ok(M, N, K) && h2_enabled())) { set_error("%s: an fp16 input operand needs the h2 wgrad kernel", what); return TOAD_ESHAPE; }
     float *slab = (float *)ws;
     int nsplit;
@@ -570,10 +570,32 @@ int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, co
     const int64_t n = N * K, n2 = db ? N : 0;
     int rgrid = (int)(((n + n2) / 4 + 255) / 256);
     if (rgrid > 4096) rgrid = 4096;
+    if (h2 && defer) {                 // the caller reduces this and its other weight gradients in one launch (launch_wgrad_reduce)
+        *defer = WgradDeferred{slab, dW, n, cs, db, n2, nsplit, beta, scales};
+        return TOAD_OK;
+    }
+    if (defer) defer->slab = nullptr;  // reduced here (not the h2 path)
     if (h2)
         hipLaunchKernelGGL(slab_reduce_h2_kernel, dim3(rgrid), dim3(256), 0, st, slab, dW, n, cs, db, n2, nsplit, beta, scales);
     else
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, st, slab, dW, n, cs, db, n2, nsplit, beta);
+    return check_launch(what);
+}
+
+int toad::launch_wgrad_reduce(const WgradDeferred *d, int count, hipStream_t st, const char *what) {
+    SlabReduceBatch b{};
+    int64_t e0 = 0;
+    for (int i = 0; i < count && b.count < 3; ++i) {
+        if (!d[i].slab) continue;
+        b.d[b.count] = SlabReduceDesc{d[i].slab, d[i].out, d[i].n, d[i].slab2, d[i].out2, d[i].n2, d[i].nsplit, d[i].beta, d[i].scales, e0};
+        e0 += (d[i].n + d[i].n2) / 4;
+        ++b.count;
+    }
+    if (b.count == 0) return TOAD_OK;
+    b.total4 = e0;
+    int grid = (int)((e0 + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(slab_reduce_h2_batch_kernel, dim3(grid), dim3(256), 0, st, b);
     return check_launch(what);
 }
 

@@ -64,7 +64,7 @@ struct Scratch {
     float *dlogits, *dsite, *dM, *loss;
     float *amax_dP, *amax_dZ2, *amax_dZ1;
     float *dP, *dZ2, *dZ1;
-    void *wgrad_ws; size_t wgrad_ws_bytes;
+    void *wgrad_ws, *wgrad_ws2, *wgrad_ws3; size_t wgrad_ws_bytes;
     size_t total;
 };
 static Scratch scratch_layout(const MilShape &s, char *base) {
@@ -104,7 +104,9 @@ static Scratch scratch_layout(const MilShape &s, char *base) {
     if (w2 > wg) wg = w2;
     if (w1 > wg) wg = w1;
     r.wgrad_ws_bytes = wg;
-    r.wgrad_ws = P(c.take(wg, big));
+    r.wgrad_ws = P(c.take(wg, big));           // one area per weight gradient: their slab reductions are deferred to ONE launch at the end
+    r.wgrad_ws2 = P(c.take(wg, big));
+    r.wgrad_ws3 = P(c.take(wg, big));
     r.total = up(c.off, 256);
     return r;
 }
@@ -213,14 +215,16 @@ static int backward_body(const MilShape &s, const Params &p, float *const *grads
         if (!(presplit && !dX)) TOAD_TRY(launch_split_h2(ops, dX ? 3 : 2, w.amax_dP, nz, st, what));
         TOAD_TRY(launch_pool_bwd(f.P, f.P + s.D, D2, f.H, p.wc, f.A_raw, f.stats, f.M, dM, dA_ext, w.dP, w.dP + s.D, D2, nullptr,
                                  grads[6], grads[7], beta, w.amax_dP, false, w.poolb_ws, w.poolb_ws_bytes, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st));
-        ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what)); ev(9);
+        WgradDeferred dw[3];
+        ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what, false, &dw[0])); ev(9);
         // dZ2 = (dP Wab + dH_pool) * (H > 0): the pooling gradient dH_pool is recomputed in the epilogue from A_raw, stats, dM
         ev(10); TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, nullptr, f.H, f.bits_h,
                                       H2Pool{f.A_raw, f.stats, dM, kT}, w.slabs, w.amax_dZ2, nullptr, st, what)); ev(11);
-        ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws, st, what)); ev(13);
+        ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws2, st, what, false, &dw[1])); ev(13);
         ev(14); TOAD_TRY(launch_nt_h2(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, f.bits_h1, nopool,
                                       w.slabs, w.amax_dZ1, nullptr, st, what)); ev(15);
-        ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, X, f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws, st, what, x_half)); ev(17);
+        ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, X, f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws3, st, what, x_half, &dw[2]));
+        TOAD_TRY(launch_wgrad_reduce(dw, 3, st, what)); ev(17);
         if (dX) TOAD_TRY(launch_nt_h2(w.dZ1, kL, w.amax_dZ1, w.planes[W_1T], w.binv[W_1T], dX, kL0, N, kL0, kL, nullptr, plain, nullptr, nullptr, nullptr, nopool,
                                       w.slabs, nullptr, nullptr, st, what));
         return TOAD_OK;
