@@ -550,6 +550,31 @@ int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, co
             hipLaunchKernelGGL(gemm_tn_f32_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, X, K, slab, cs, (int)M,
                                (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
         rc = check_launch(what);
+#ifdef TOAD_H2_TRACE
+        if (h2 && getenv("TOAD_TN_TRACE")) {                // tracing build: print the timing summary of this launch
+            static unsigned long long hb[2048];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpyFromSymbol(hb, HIP_SYMBOL(g_tn_trace), sizeof(hb));
+            double cmin = 1e30, cmax = 0, csum = 0, rmin = 1e30, rmax = 0, r0 = 1e30, r1 = 0;
+            for (int b = 0; b < PB_GRID; ++b) {
+                const double c = (double)(hb[b * 4 + 1] - hb[b * 4]), r = (double)(hb[b * 4 + 3] - hb[b * 4 + 2]) / 100.0;
+                cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax; csum += c; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax;
+                r0 = (double)hb[b * 4 + 2] < r0 ? (double)hb[b * 4 + 2] : r0; r1 = (double)hb[b * 4 + 3] > r1 ? (double)hb[b * 4 + 3] : r1;
+            }
+            double per = 0; int np = 0;
+            for (int i = 1; i < 64; ++i) if (hb[1024 + i] > hb[1024 + i - 1]) { per += (double)(hb[1024 + i] - hb[1024 + i - 1]); ++np; }
+            fprintf(stderr, "[tn trace] %s M=%lld N=%lld K=%lld: workgroup cycles min %.0f mean %.0f max %.0f | us min %.1f max %.1f | first start -> last end %.1f us | "
+                    "step period %.0f cycles (%d samples) | epilogue of workgroup 0: %.0f cycles after step %llu\n", what, (long long)M, (long long)N, (long long)K,
+                    cmin, csum / PB_GRID, cmax, rmin, rmax, (r1 - r0) / 100.0, np ? per / np : 0.0, np, (double)(hb[1101] - hb[1100]), hb[1102]);
+#if TOAD_H2_TRACE == 1
+            for (int w = 0; w < 2; ++w) {               // phase means over steps 8..23: stage loads | k16 step 0 | k16 step 1 + staging | barrier | first fragment reads
+                double ph[5] = {0, 0, 0, 0, 0};
+                for (int i = 0; i < 16; ++i) { const unsigned long long *tr = hb + 1200 + (i * 2 + w) * 6; for (int k = 0; k < 5; ++k) ph[k] += (double)(tr[k + 1] - tr[k]) / 16.0; }
+                fprintf(stderr, "[tn trace]    wave %d: stage_load issue %.0f | k16 step 0 %.0f | k16 step 1 + staging %.0f | barrier %.0f | fragment reads %.0f\n", w ? 5 : 0, ph[0], ph[1], ph[2], ph[3], ph[4]);
+            }
+#endif
+        }
+#endif
     } else {
         static bool attr_set = false;
         if (!attr_set) {
