@@ -200,6 +200,9 @@ def gemm_roofline(timing, n_patches_per_set):
             "fp16_mfma_tflops_issued": round(tf * SPLIT_TERMS / 1e12, 1),
             "frac_of_round1_six_term_ceiling_416.7": round(tf / (MFMA_F16_PEAK / 6), 4),
             "fp32_mfma_peak_for_reference": 157.3,
+            # tools/ubench/mfma_power (profiles/r02av): the matrix pipe ALONE, on random fp16 operands, sustains 1735 of the nominal 2500
+            # TFLOP/s (1.7 GHz; the nominal rate needs zeros) - context for `frac`, which stays against the nominal peak
+            "frac_of_measured_mfma_only_rate_578": round(tf / (1735e12 / SPLIT_TERMS), 4),
             "algorithmic_flops": GEMM_FLOP_PER_PATCH * n_patches_per_set, "us_per_slide": round(gemm_t * 1e6, 1)}
 
 
