@@ -90,9 +90,11 @@ def test_two_ranks_on_the_real_kernels(cuda, balanced):
     g_single = dp.flat_grad.cpu().clone()
     dp.step(slides, len(LENS))
     assert (g_single - g0).abs().max().item() <= 1e-6 * max(g_single.abs().max().item(), 1e-30) + 1e-9
-    # two Adam steps at lr 1e-3: Adam's update is ~lr * g/|g| for small gradients, so round-off-level gradient differences
-    # (summation order of the two partial buckets) move a parameter by up to a few 1e-3 of one step
-    assert (model.flat_parameters().cpu() - p0).abs().max().item() <= 2e-5
+    # two Adam steps at lr 1e-3: Adam's update is ~lr * g/|g|, so a round-off-level gradient difference (summation order of the two
+    # partial buckets) on a near-zero gradient can move that one parameter by up to lr per step. Hold almost all parameters tight and
+    # every parameter inside what two sign flips can do. (The default kernels keep ALL within 2e-5; the TOAD_GEMM_H2=0 arm does not.)
+    dpar = (model.flat_parameters().cpu() - p0).abs()
+    assert dpar.max().item() <= 2 * 2 * 1e-3 and (dpar > 2e-5).float().mean().item() <= 1e-3, (dpar.max().item(), (dpar > 2e-5).float().mean().item())
 
     # (iii) reduced gradient == mean of the oracle's per-slide gradients (fp64 yardstick for ReLU-boundary flips)
     offs, _ = model.flat_offsets()
