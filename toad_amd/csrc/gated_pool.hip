@@ -522,16 +522,18 @@ __global__ __launch_bounds__(256) void bwd_partial_reduce_kernel(const float *__
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static int pool_grid(int64_t N) {
+// Workgroups of the two pool kernels (each persistent over row steps, 4 waves). Two per CU: with one, a CU's four waves issue a step's
+// ten 16-byte loads per lane, wait, compute, store - the memory pipe idles during the compute; a second workgroup fills it
+// (rocprofv3, 100k patches: forward 84 -> 75 us = 6.85 TB/s, backward 172 -> 140 us; three per CU is slower again, profiles/r02ba_*).
+static int pool_grid(int64_t N, bool bwd = false) {
     const int64_t ntiles = (N + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP;
-    static int64_t cap = 0;        // one 4-wave block per CU: the kernel runs at the per-CU load-path ceiling
-                                   // (~10 B/clk/CU) from one wave per SIMD; more blocks only add merge overhead
-    if (cap == 0) {
-        const char *e = getenv("TOAD_POOL_GRID");      // tuning knob (tools/kernel_bench.py sweeps it)
-        cap = e ? atoll(e) : 256;
-        if (cap < 1) cap = 256;
+    static int64_t cap[2] = {0, 0};
+    if (cap[bwd] == 0) {
+        const char *e = getenv(bwd ? "TOAD_POOL_BWD_GRID" : "TOAD_POOL_GRID");      // tuning knobs
+        cap[bwd] = e ? atoll(e) : 512;
+        if (cap[bwd] < 1) cap[bwd] = 512;
     }
-    return (int)(ntiles < cap ? ntiles : cap);
+    return (int)(ntiles < cap[bwd] ? ntiles : cap[bwd]);
 }
 
 static bool shape_ok(int L, int D, int T) {
@@ -618,7 +620,7 @@ extern "C" int toad_gated_pool_fwd_f32(const float *Pa, const float *Pb, int64_t
     return check_launch(what);
 }
 
-static size_t bwd_partials_bytes(int64_t N, int D, int T) { return ((size_t)pool_grid(N) * (size_t)bwd_partial_floats(D, T) * sizeof(float) + 255) & ~(size_t)255; }
+static size_t bwd_partials_bytes(int64_t N, int D, int T) { return ((size_t)pool_grid(N, true) * (size_t)bwd_partial_floats(D, T) * sizeof(float) + 255) & ~(size_t)255; }
 static int64_t bwd_fine_floats(int64_t N) { return ((N + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP) * NW; }
 extern "C" size_t toad_gated_pool_bwd_ws_bytes(int64_t N, int L, int D, int T) {
     if (N <= 0 || !shape_ok(L, D, T)) return 0;
@@ -639,7 +641,7 @@ int toad::launch_pool_bwd(const float *Pa, const float *Pb, int64_t ldp, const f
     if (ldp < D || ldp % 4 != 0 || ldd < D || ldd % 4 != 0) { set_error("%s: bad row stride", what); return TOAD_ESHAPE; }
     if (!aligned16(Pa) || !aligned16(Pb) || !aligned16(H) || !aligned16(dPa) || !aligned16(dPb) || (dH && !aligned16(dH)) || !aligned16(ws)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
     if (ws_bytes < toad_gated_pool_bwd_ws_bytes(N, L, D, T)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
-    const int grid = pool_grid(N);
+    const int grid = pool_grid(N, true);
     static_assert(H2_ROWBLK % ROWS_PER_BLOCK_STEP == 0, "a block step must not straddle two abs-max blocks");
     (void)zero_amax;                                   // every slot is overwritten (no atomics): nothing to zero
     float *fine = dp_amax ? reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + bwd_partials_bytes(N, D, T)) : nullptr;
