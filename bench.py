@@ -1,9 +1,10 @@
 """bench.py — benchmarks of the TOAD gated-attention MIL hot path on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 3                      # headline (the driver's run)
+    python bench.py --gpus N --steps K --warmup W                        # N > 1 started plainly: re-executes itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
-    python bench.py --config 2 | 3 | 4 [--gpus N]                        # BASELINE.json configs 2-4
+        --master-port P bench.py --gpus N --steps K --warmup W           # (what the driver runs for N > 1; same thing)
+    python bench.py --config 2 | 3 | 4 | 5 [--gpus N]                    # BASELINE.json configs 2-5 (5 = bench_extract.py)
     python bench.py --dropin [--patches N]                               # the reference's own call sequence, timed
 
 Headline (no --config). A "step" = one optimiser step of slide-sharded data parallel training: every rank runs
@@ -18,8 +19,10 @@ step / max-over-ranks step time). Weak scaling. The JSON line also carries
                  csrc/gemm_h2.inc), so the ceiling is the dense fp16 peak / 3 = 833.3 TFLOP/s fp32-equivalent (the issued
                  fp16 MFMA rate is reported next to it; round 1's six-term bf16 form had 416.7, the exact-fp32 MFMA peak is
                  157.3);
-  sustained      the same step repeated for >= 2 s right after the timed region (the K = 20 default lasts ~50 ms, shorter than
-                 the clock governor's settling time);
+  sustained      the same step repeated for >= 8 s right after the timed region (the K = 20 default lasts ~50 ms, shorter than
+                 the clock governor's settling time and than the sampling period of an external utilisation monitor);
+  allreduce      the 4.77 MB flat-gradient all-reduce over RCCL on the launch stream, HIP-event timed (at N = 1 a world-1 RCCL
+                 communicator is created for it: the collective path executes on the one GPU there is);
   dropin         the reference's own call sequence on the same bag: model(data, sex), torch CrossEntropyLoss x2,
                  loss.backward(), torch.optim.Adam(model.parameters()).step(), zero_grad()
                  (utils/core_utils_mtl_concat.py:206-234), which is what a reference user gets without touching the harness;
@@ -91,12 +94,15 @@ def _cpu_name() -> str:
     return "unknown"
 
 
+POOL_TRAFFIC_FILE = "r03_pool_traffic.json"     # re-measured whenever the pool kernels change (tools/pmc_pool_traffic.sh writes it)
+
+
 def measured_pool_traffic(n: int):
-    """HBM bytes per launch of the fused pool forward from the committed rocprofv3 PMC passes
-    (profiles/r01_pool_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the
-    gfx950 guide prescribes for 16-B/lane streaming loads). Only valid for the N it was measured at (the kernel is unchanged)."""
+    """HBM bytes per launch of the fused pool forward from THIS round's committed rocprofv3 PMC passes
+    (profiles/r03_pool_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the gfx950 guide prescribes
+    for 16-B/lane streaming loads). Only valid for the N and the kernel build it was measured at; None (JSON null) otherwise."""
     try:
-        with open(os.path.join(REPO, "profiles", "r01_pool_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", POOL_TRAFFIC_FILE)) as f:
             t = json.load(f)
         if int(t["patches"]) == int(n):
             return float(t["pool_fwd_hbm_bytes_per_launch"])
@@ -240,6 +246,32 @@ def time_dropin(n: int, steps: int, warmup: int, dev, host_reads: bool):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def time_allreduce(dp, dev, world: int, backend: str):
+    """The gradient all-reduce of a step, alone: dist.all_reduce(SUM) of the flat fp32 bucket on the launch stream, HIP-event
+    timed over 20 launches after 5 warm-ups. At world 1 (the driver's default run) a one-rank RCCL communicator is created
+    first, so the collective path executes on hardware even when only one GPU exists; failures are reported, never raised."""
+    info = {"bytes": int(dp.flat_grad.numel() * 4), "backend": "nccl (RCCL)" if backend == "nccl" else backend, "world": world}
+    try:
+        if not dist.is_initialized():
+            from toad_amd import launch
+            launch.init_process_group(backend, device=dev if backend == "nccl" else None, timeout_s=60)
+            info["communicator"] = "created for this measurement (world 1)"
+        buf = dp.flat_grad.clone()
+        for _ in range(5):
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for a, b in evs:
+            a.record(); dist.all_reduce(buf, op=dist.ReduceOp.SUM); b.record()
+        torch.cuda.synchronize()
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+        info.update({"us": round(us[len(us) // 2], 2), "us_min": round(us[0], 2), "launches": len(us),
+                     "unchanged_at_world_1": bool(world > 1 or torch.equal(buf, dp.flat_grad))})
+    except Exception as e:                                   # noqa: BLE001 - a bench line is still worth printing without it
+        info["error"] = f"{type(e).__name__}: {e}"[:300]
+    return info
+
+
 def run_config2(args, dev):
     """Pool forward only, one resident 100k-patch bag (BASELINE config 2)."""
     from toad_amd import ops
@@ -284,7 +316,8 @@ def main():
                          "reported under its own metric name, BASELINE's configurations are fp32")
     ap.add_argument("--patches", type=int, default=0, help="patches per slide (default: 100,000; config 3: 10,000; config 4: 50,000)")
     ap.add_argument("--slides-per-rank", type=int, default=1)
-    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4], help="BASELINE.json config (0 = the headline step)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE.json config (0 = the headline step; 5 = bench_extract.py)")
+    ap.add_argument("--sustain-seconds", type=float, default=8.0, help="length of the sustained leg after the timed region (0 = skip)")
     ap.add_argument("--dropin", action="store_true", help="time only the reference's call sequence on the drop-in module")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="headline run without the extra drop-in timing")
@@ -295,22 +328,27 @@ def main():
     global BAG_DTYPE
     BAG_DTYPE = torch.float16 if args.bag_dtype == "fp16" else torch.float32
 
+    from toad_amd import launch
+    if args.config == 5:                                   # BASELINE config 5 lives in bench_extract.py (same contract, same flags)
+        import bench_extract
+        sys.argv = [os.path.join(REPO, "bench_extract.py"), "--gpus", str(args.gpus)] + \
+                   (["--steps", str(args.steps)] if "--steps" in sys.argv else []) + \
+                   (["--warmup", str(args.warmup)] if "--warmup" in sys.argv else []) + \
+                   (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+        return bench_extract.main()
+    # `python bench.py --gpus N` started plainly: spawn the N ranks (torch.distributed.run, 127.0.0.1) and exit with their code
+    launch.maybe_self_launch(__file__, sys.argv[1:], args.gpus, single_device=args.single_device)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one process per GPU (or run `python bench.py --gpus N` plainly)")
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        launch.init_process_group(args.backend, device=dev if args.backend == "nccl" else None)
 
     if args.config == 2:
         return run_config2(args, dev)
@@ -377,9 +415,10 @@ def main():
     sync()
     last_loss = float(losses[-1][0].item()) * global_slides
 
-    # sustained rate: keep stepping for >= 2 s (same barrier + synchronize bracketing)
+    # sustained rate: keep stepping for >= --sustain-seconds (same barrier + synchronize bracketing); long enough for the clock
+    # governor to settle and for an external utilisation sampler (the driver's gpu_busy) to land inside it
     sus_steps, sus_t = 0, 0.0
-    if args.config in (0, 3):
+    if args.config in (0, 3) and args.sustain_seconds > 0:
         chunk = max(args.steps, 10)
         sync()
         t1 = time.perf_counter()
@@ -389,16 +428,17 @@ def main():
             sync()
             sus_steps += chunk
             sus_t = time.perf_counter() - t1
-            flag = torch.tensor([1.0 if sus_t >= 2.0 else 0.0], device=dev)
+            flag = torch.tensor([1.0 if sus_t >= args.sustain_seconds else 0.0], device=dev)
             if world > 1:
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)             # every rank leaves the loop together
-            if flag.item() > 0 or sus_steps >= 5000:
+            if flag.item() > 0 or sus_steps >= 200000:
                 break
 
     if world > 1:
         t = torch.tensor([elapsed, sus_t], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, sus_t = float(t[0].item()), float(t[1].item())
+    allreduce = time_allreduce(dp, dev, world, args.backend)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -413,7 +453,8 @@ def main():
             "metric": metric,
             "value": round(value, 3), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "f32" if args.bag_dtype == "fp32" else "f32 (bag stored as f16)", "data": "synthetic",
+            "dtype": "f32 (storage + accumulation; GEMM operands as 2 x f16 pieces, 3 MFMA terms)" + ("" if args.bag_dtype == "fp32" else "; bag stored as f16"),
+            "data": "synthetic",
             "config": {"workload": f"TOAD_fc_mtl_concat(big, n_classes=18) fwd + 0.75/0.25 CE + bwd + Adam on "
                                    f"{len(slides[0])} x {n}-patch x 1024-d N(0,1) bag(s) per GPU per step, bags resident in HBM"
                                    + (f"; 64 slides per optimiser step dealt round robin over {world} rank(s)" if args.config == 4 else ""),
@@ -436,6 +477,7 @@ def main():
         if sus_steps:
             out["sustained"] = {"value": round(global_slides * sus_steps / sus_t, 3), "unit": "slides/s", "steps": sus_steps,
                                 "seconds": round(sus_t, 3), "ms_per_step": round(sus_t / sus_steps * 1e3, 3)}
+        out["allreduce"] = allreduce
         out["last_loss"] = round(last_loss, 5)
         if world == 1 and args.config in (0, 3) and not args.no_dropin:
             k = max(args.steps, 10)
@@ -449,7 +491,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline_step(n, budget_s=30.0 if n >= 50_000 else 15.0, min_reps=3 if n >= 50_000 else 10)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOAD_ABI_VERSION 8
+#define TOAD_ABI_VERSION 9
 
 enum { TOAD_OK = 0, TOAD_EINVAL = -1, TOAD_ESHAPE = -2, TOAD_EWORKSPACE = -3, TOAD_EALIGN = -4 };
 enum { TOAD_ACT_NONE = 0, TOAD_ACT_RELU = 1 };
@@ -342,6 +342,35 @@ int toad_mil_step_x16_f32(const float *const *params, float *const *grads, float
                           float drop_p, uint64_t seed,
                           float *loss_out, float *logits_out, float *site_logits_out,
                           void *ws, size_t ws_bytes, void **events, void *stream);
+
+/* ---- prepared bags (ABI 9) -------------------------------------------------------------------------------------------------
+ * A slide's bag is an INPUT, constant across epochs (datasets/dataset_mtl_concat.py:369-373 loads the same .pt file every time
+ * the slide comes up), and the two products that read it - the first Linear (models/model_toad.py:59) and its weight gradient
+ * (utils/core_utils_mtl_concat.py:231) - are a third of a step's flops. toad_bag_prepare_f32 converts the fp32 bag X [N,K] ONCE,
+ * at ingest, into the form those products consume directly: its two fp16 pieces (x * 2^k = h + m, one exponent k per block of 256
+ * rows) stored plane-tiled in the GEMMs' LDS stage order (csrc/gemm_pt.inc). Same 4 bytes per element as fp32 (the caller may then
+ * drop the fp32 copy), bitwise the results of the fp32 calls (the same pieces, products and accumulation order - only nobody has to
+ * re-derive the pieces every step), no per-step abs-max pass over the bag.
+ *   planes : toad_bag_planes_bytes(N, K) bytes, 16-byte aligned; amax : toad_amax_floats(N) floats (the bag's abs-max array).
+ * The *_xp_* calls are toad_mil_{fwd,bwd,step}_f32 with (Xp, x_amax) in place of X; dX is not available (the bag is data). */
+size_t toad_bag_planes_bytes(int64_t N, int64_t K);
+int toad_bag_prepare_f32(const float *X, int64_t N, int64_t K, void *planes, float *amax, void *stream);
+/* toad_linear_wgrad_f32 with the layer input given as a prepared (plane-tiled) operand Xp [M,K] + its abs-max array (required). */
+int toad_linear_wgrad_xp_f32(const float *dY, const void *Xp, const float *x_amax, float *dW, float *db, int64_t M, int64_t N,
+                             int64_t K, float beta, const float *dy_amax, void *ws, size_t ws_bytes, void *stream);
+int toad_mil_fwd_xp_f32(const float *const *params, const void *Xp, const float *x_amax, const float *sex, int64_t N, int C, int D,
+                        float drop_p, uint64_t seed, int attention_only,
+                        void *arena, size_t arena_bytes, void *scratch, size_t scratch_bytes, void *stream);
+int toad_mil_bwd_xp_f32(const float *const *params, float *const *grads, float beta, const void *Xp, const float *x_amax,
+                        int64_t N, int C, int D, float drop_p, uint64_t seed, const void *arena, size_t arena_bytes,
+                        const float *dlogits, const float *dsite, const float *dA_ext, const float *dMcat_ext,
+                        float *dsex, void *scratch, size_t scratch_bytes, void *stream);
+int toad_mil_step_xp_f32(const float *const *params, float *const *grads, float beta, const void *Xp, const float *x_amax,
+                         const float *sex, const int64_t *label, const int64_t *site,
+                         float w_cls, float w_site, int64_t N, int C, int D,
+                         float drop_p, uint64_t seed,
+                         float *loss_out, float *logits_out, float *site_logits_out,
+                         void *ws, size_t ws_bytes, void **events, void *stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TOAD_HIP_LIB", os.path.join(_HERE, "libtoad_hip.so"))   # override: kernel A/B builds only
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 P, I64, I, F, SZ, U64 = c_void_p, c_int64, c_int, c_float, c_size_t, c_uint64
 
@@ -62,6 +62,12 @@ SIGNATURES = {
     "toad_mil_fwd_x16_f32": (I, [P, P, P, I64, I, I, F, U64, I, P, SZ, P, SZ, P]),
     "toad_mil_bwd_x16_f32": (I, [P, P, F, P, I64, I, I, F, U64, P, SZ, P, P, P, P, P, P, SZ, P]),
     "toad_mil_step_x16_f32": (I, [P, P, F, P, P, P, P, F, F, I64, I, I, F, U64, P, P, P, P, SZ, P, P]),
+    "toad_bag_planes_bytes": (SZ, [I64, I64]),
+    "toad_bag_prepare_f32": (I, [P, I64, I64, P, P, P]),
+    "toad_linear_wgrad_xp_f32": (I, [P, P, P, P, P, I64, I64, I64, F, P, P, SZ, P]),
+    "toad_mil_fwd_xp_f32": (I, [P, P, P, P, I64, I, I, F, U64, I, P, SZ, P, SZ, P]),
+    "toad_mil_bwd_xp_f32": (I, [P, P, F, P, P, I64, I, I, F, U64, P, SZ, P, P, P, P, P, P, SZ, P]),
+    "toad_mil_step_xp_f32": (I, [P, P, F, P, P, P, P, P, F, F, I64, I, I, F, U64, P, P, P, P, SZ, P, P]),
 }
 
 _lib = None

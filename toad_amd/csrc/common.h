@@ -85,6 +85,11 @@ __device__ __forceinline__ void st4s(float *p, f32x4 v) {
 #endif
 }
 
+// how the bag (the A operand of the first Linear, the B operand of its weight gradient) lies in memory
+enum { TOAD_X_F32 = 0,      // fp32 [N][1024]
+       TOAD_X_F16 = 1,      // fp16 [N][1024] (feature stores kept in half precision)
+       TOAD_X_PT = 2 };     // plane-tiled two-piece form written by toad_bag_prepare_f32 (csrc/gemm_pt.inc)
+
 // ---- host-side launchers of the fp16 two-piece GEMMs (defined in gemm_f32.hip next to their kernels; used by step.hip) ----
 struct H2Operand { const float *src; int64_t sn, sk; int64_t N, K; unsigned short *planes; float *binv; };   // B[n,k] = src[n*sn + k*sk]
 struct H2Pool { const float *a_raw, *stats, *dM; int T; };                                                   // recomputed pooling addend (T = 0: none)
@@ -99,14 +104,16 @@ int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax,
 int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C,
                  int64_t ldc, int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
                  const float *mask_src, const unsigned long long *mask_bits, H2Pool pool, float *slabs, float *y_amax,
-                 unsigned long long *bits_out, hipStream_t st, const char *what, bool a_half = false);
+                 unsigned long long *bits_out, hipStream_t st, const char *what, int a_mode = TOAD_X_F32);
+size_t pt_bytes_host(int64_t rows, int64_t cols);                                                          // bytes of a plane-tiled tensor
+int launch_pt_split(const float *X, int64_t ld, int64_t M, int64_t K, const float *amax, unsigned short *pt, hipStream_t st, const char *what);
 int launch_pool_bwd(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *A_raw, const float *stats,
                     const float *M, const float *dM, const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH, float *dWc, float *dbc,
                     float beta, float *dp_amax, bool zero_amax, void *ws, size_t ws_bytes, int64_t N, int L, int D, int T, float drop_p,
                     uint64_t seed_a, uint64_t seed_b, hipStream_t st);
 struct WgradDeferred;
 int launch_wgrad(const float *dY, const float *dy_amax, const float *X, const float *x_amax, float *dW, float *db, int64_t M,
-                 int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what, bool x_half = false,
+                 int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what, int x_mode = TOAD_X_F32,
                  struct WgradDeferred *defer = nullptr);
 // a weight gradient whose slab reduction was deferred (launch_wgrad with `defer`): up to three are reduced by ONE launch_wgrad_reduce
 struct WgradDeferred { const float *slab; float *out; int64_t n; const float *slab2; float *out2; int64_t n2; int nsplit; float beta; const float *scales; };

@@ -22,6 +22,7 @@
 #include "common.h"
 
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 
 namespace toad {
@@ -50,16 +51,65 @@ __device__ __forceinline__ bool map_tile(int tiles_m, int tiles_n, int &tm, int 
 #include "gemm_nt_split.inc"
 #include "gemm_tn.inc"
 #include "gemm_h2.inc"
+#include "gemm_pt.inc"
 #include "gemm_narrow.inc"
 
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static int narrow_enabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("TOAD_GEMM_NARROW"); v = e ? atoi(e) : 1; }   // A/B knob; default on
-    return v;
+// One-time initialisation of this translation unit: kernel attributes (dynamic LDS sizes) and the dispatch configuration.
+// The shipped library has ONE arithmetic per product shape and reads no environment variable on any dispatch path; a build
+// with -DTOAD_AB_KNOBS (toad_amd.build.build(defines=("TOAD_AB_KNOBS",), tag="_ab"), selected at run time with TOAD_HIP_LIB)
+// additionally compiles round 1's exact-fp32 / split-bf16 arms of the MIL GEMMs and lets TOAD_GEMM_* / TOAD_EXTRACT_H2 /
+// TOAD_NARROW_RES_KMAX choose them, for A/B measurements. std::call_once makes the first call from any thread complete the
+// attribute calls before any launch (PyTorch runs backward on its own thread; the ingest workers are threads too).
+struct GemmCfg { int narrow, narrow_res_kmax, h2, big, split, ext_h2; };
+#ifdef TOAD_AB_KNOBS
+static int ab_knob(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static constexpr int ab_knob(const char *, int dflt) { return dflt; }
+#endif
+static GemmCfg g_cfg;
+static std::once_flag g_cfg_once;
+static const GemmCfg &cfg() {
+    std::call_once(g_cfg_once, [] {
+        g_cfg.narrow = ab_knob("TOAD_GEMM_NARROW", 1);
+        // measured (tools/gemm_shape_bench.py, same box): M=262144 K=64 N=256 +residual 170 -> 133 us on the 256x128 narrow tiles
+        // (16 residual rows in flight per wave); K=128 equal, K=256 slower (A is re-split per 128-column tile) -> 64
+        g_cfg.narrow_res_kmax = ab_knob("TOAD_NARROW_RES_KMAX", 64);
+        g_cfg.h2 = ab_knob("TOAD_GEMM_H2", 1);
+        g_cfg.big = ab_knob("TOAD_GEMM_BIG", 1);
+        g_cfg.split = ab_knob("TOAD_GEMM_SPLIT", 1);
+        g_cfg.ext_h2 = ab_knob("TOAD_EXTRACT_H2", 1);
+#define TOAD_ATTR(K, BYTES) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES)
+#define TOAD_H2_ATTR(P, A_, M_) TOAD_ATTR((gemm_nt_h2_big_kernel<P, A_, M_, 0>), H2_SMEM)
+        TOAD_H2_ATTR(false, false, 0); TOAD_H2_ATTR(false, false, 1); TOAD_H2_ATTR(false, false, 2);
+        TOAD_H2_ATTR(true, false, 0); TOAD_H2_ATTR(true, false, 1); TOAD_H2_ATTR(true, false, 2);
+        TOAD_H2_ATTR(false, true, 0); TOAD_H2_ATTR(false, true, 1);
+#undef TOAD_H2_ATTR
+        TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 1>), H2_SMEM);
+        TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 2>), H2_SMEM_PT);
+        TOAD_ATTR(gemm_tn_h2_big_kernel<false>, TN2_SMEM);
+        TOAD_ATTR(gemm_tn_h2_big_kernel<true>, TN2_SMEM);
+        TOAD_ATTR(gemm_tn_pt_kernel, TP_SMEM);
+        TOAD_ATTR(gemm_nt_f32_kernel, NT_SMEM);
+        TOAD_ATTR(gemm_tn_f32_kernel, TN_SMEM);
+        TOAD_ATTR(gemm_nt_split_big_kernel, SP_SMEM);
+        TOAD_ATTR((gemm_nt_split_narrow_kernel<2, 2, GATHER_NONE>), (NarrowCfg<2, 2>::SMEM));
+        TOAD_ATTR((gemm_nt_split_narrow_kernel<1, 4, GATHER_NONE>), (NarrowCfg<1, 4>::SMEM));
+        TOAD_ATTR((gemm_nt_split_narrow_kernel<2, 2, GATHER_CONV>), (NarrowCfg<2, 2>::SMEM));
+        TOAD_ATTR((gemm_nt_split_narrow_kernel<1, 4, GATHER_CONV>), (NarrowCfg<1, 4>::SMEM));
+        TOAD_ATTR((gemm_nt_split_narrow_kernel<2, 2, GATHER_STEM>), (NarrowCfg<2, 2>::SMEM));
+#ifdef TOAD_AB_KNOBS
+        TOAD_ATTR(gemm_nt_f32_big_kernel, PB_SMEM);
+        TOAD_ATTR(gemm_tn_f32_big_kernel, PB_SMEM);
+        TOAD_ATTR(gemm_tn_split_big_kernel, PB_SMEM);
+#endif
+#undef TOAD_ATTR
+    });
+    return g_cfg;
 }
+static int narrow_enabled() { return cfg().narrow; }
 
 // C[M,N] = act(A' W^T + bias + addend) with N <= 128 on the narrow kernels; A' = A[M,K] (geom == nullptr) or the implicit
 // im2col of the NHWC activation A described by *geom. `ws` as for launch_nt (the bf16 planes live behind the slab area).
@@ -68,12 +118,7 @@ static int launch_narrow_t(const float *A, int64_t lda, const float *W, int64_t 
                            int64_t K, const float *bias, int relu, const float *addend, const ConvGeom &cg, void *ws,
                            hipStream_t st, const char *what) {
     using Cfg = NarrowCfg<RA, NB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_split_narrow_kernel<RA, NB, MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
-        attr_set = true;
-    }
+    (void)cfg();
     const int tiles_m = (int)((M + Cfg::TM - 1) / Cfg::TM), tiles_n = (int)((N + Cfg::TN - 1) / Cfg::TN);
     unsigned short *planes = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(ws) + (size_t)PB_GRID * PB * PB * sizeof(float));
     const int64_t pthreads = (int64_t)tiles_n * (K / BK) * Cfg::TN * 4;
@@ -87,13 +132,7 @@ static int launch_narrow_t(const float *A, int64_t lda, const float *W, int64_t 
     return check_launch(what);
 }
 
-static int narrow_res_kmax() {
-    static int v = -1;
-    // measured (tools/gemm_shape_bench.py, same box): M=262144 K=64 N=256 +residual 170 -> 133 us on the 256x128 narrow tiles
-    // (16 residual rows in flight per wave); K=128 equal, K=256 slower (A is re-split per 128-column tile) -> default 64
-    if (v < 0) { const char *e = getenv("TOAD_NARROW_RES_KMAX"); v = e ? atoi(e) : 64; }
-    return v;
-}
+static int narrow_res_kmax() { return cfg().narrow_res_kmax; }
 static bool narrow_ok(int64_t M, int64_t N, int64_t K, int64_t ldc, const float *bias, const float *addend, void *ws) {
     const bool wide_ok = addend && K <= narrow_res_kmax();       // residual GEMMs with a short reduction: epilogue-bound, see DESIGN 10
     return narrow_enabled() && ws && (N <= 128 || wide_ok) && N % 4 == 0 && K % BK == 0 && ldc % 4 == 0 && M < (1ll << 31) &&
@@ -101,22 +140,7 @@ static bool narrow_ok(int64_t M, int64_t N, int64_t K, int64_t ldc, const float 
 }
 
 // ---- h2 (fp16 two-piece) path ---------------------------------------------------------------------------------
-static int h2_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("TOAD_GEMM_H2");             // A/B knob; default on
-        v = e ? atoi(e) : 1;
-#define TOAD_H2_ATTR(P, A_, M_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_h2_big_kernel<P, A_, M_>), hipFuncAttributeMaxDynamicSharedMemorySize, H2_SMEM)
-        TOAD_H2_ATTR(false, false, 0); TOAD_H2_ATTR(false, false, 1); TOAD_H2_ATTR(false, false, 2);
-        TOAD_H2_ATTR(true, false, 0); TOAD_H2_ATTR(true, false, 1); TOAD_H2_ATTR(true, false, 2);
-        TOAD_H2_ATTR(false, true, 0); TOAD_H2_ATTR(false, true, 1);
-#undef TOAD_H2_ATTR
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_h2_big_kernel<false, false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H2_SMEM);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_h2_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TN2_SMEM);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_h2_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TN2_SMEM);
-    }
-    return v;
-}
+static int h2_enabled() { return cfg().h2; }
 // shapes the persistent h2 NT kernel serves (32-bit row offsets of A, whole 32-deep stages, 16-byte output rows)
 bool h2_nt_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc) {
     return h2_enabled() && M >= 1 && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && lda % 4 == 0 && (uint64_t)M * lda * 4 < (1ull << 32);
@@ -153,15 +177,28 @@ int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax,
     hipLaunchKernelGGL(absmax_rows256_kernel, dim3(nblk <= 8 ? 16 : 4, nblk), dim3(256), 0, st, X, ld, (int)M, (int)K, amax);
     return check_launch(what);
 }
+size_t pt_bytes_host(int64_t rows, int64_t cols) { return pt_bytes(rows, cols); }
+// X [M][K] fp32 -> plane-tiled form (gemm_pt.inc) with the per-row-tile exponents of `amax` (its toad_absmax_rows256_f32 array)
+int launch_pt_split(const float *X, int64_t ld, int64_t M, int64_t K, const float *amax, unsigned short *pt, hipStream_t st, const char *what) {
+    hipLaunchKernelGGL(pt_split_kernel, dim3((unsigned)pt_col_stages(K), (unsigned)pt_row_tiles(M)), dim3(256), 0, st, X, ld, (int)M, (int)K, amax, pt,
+                       (int)pt_col_stages(K));
+    return check_launch(what);
+}
 // C = epi(A . B^T) with pre-split B (planes + binv) and the abs-max array of A; y_amax (zeroed by the caller) receives the abs-max of C
 int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C,
                         int64_t ldc, int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
                         const float *mask_src, const unsigned long long *mask_bits, H2Pool pool, float *slabs, float *y_amax,
-                        unsigned long long *bits_out, hipStream_t st, const char *what, bool a_half) {
+                        unsigned long long *bits_out, hipStream_t st, const char *what, int a_mode) {
     const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
-    if (a_half) {          // A is fp16 [M, lda halves]: plain forward only (no addend / mask / pooling variants are instantiated)
-        if (addend || mask_src || mask_bits || pool.T > 0) { set_error("%s: the fp16-operand kernel has no addend / mask / pooling epilogue", what); return TOAD_EINVAL; }
-        hipLaunchKernelGGL((gemm_nt_h2_big_kernel<false, false, 0, true>), dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, (const float *)nullptr, planes,
+    (void)cfg();
+    if (a_mode != TOAD_X_F32) {   // A is fp16 [M, lda halves] or plane-tiled: plain forward only (no addend / mask / pooling variants are instantiated)
+        if (addend || mask_src || mask_bits || pool.T > 0) { set_error("%s: the fp16 / plane-tiled operand kernels have no addend / mask / pooling epilogue", what); return TOAD_EINVAL; }
+        if (a_mode == TOAD_X_PT)
+            hipLaunchKernelGGL((gemm_nt_h2_big_kernel<false, false, 0, 2>), dim3(PB_GRID), dim3(512), H2_SMEM_PT, st, A, lda, a_amax, planes,
+                               binv, C, ldc, (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                               (const float *)nullptr, (const float *)nullptr, 0, slabs, y_amax, bits_out, tiles_m, tiles_n);
+        else
+        hipLaunchKernelGGL((gemm_nt_h2_big_kernel<false, false, 0, 1>), dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, (const float *)nullptr, planes,
                            binv, C, ldc, (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
                            (const float *)nullptr, (const float *)nullptr, 0, slabs, y_amax, bits_out, tiles_m, tiles_n);
         int rc16 = check_launch(what);
@@ -170,11 +207,12 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
         for (int x = 0; x < kNumXCD; ++x) { const NtPlan pl = nt_plan(x, tiles_m, tiles_n, (int)(K / BK)); if (pl.g > 1) { rem_all16 += pl.rem; if (pl.rem > max_rem16) max_rem16 = pl.rem; } }
         if (max_rem16 > 0) {   // the fix-up takes the A scale from a_amax: fp16 operands carry scale 1 -> NULL selects exponent 0
             const H2Pool np{nullptr, nullptr, nullptr, 0};
+            const float *fx_amax = a_mode == TOAD_X_PT ? a_amax : nullptr;
             if (rem_all16 > 8)
-                hipLaunchKernelGGL(nt_fixup_h2_kernel<4>, dim3(16, max_rem16, kNumXCD), dim3(256), 0, st, (const float *)slabs, (const float *)nullptr, binv, C, ldc,
+                hipLaunchKernelGGL(nt_fixup_h2_kernel<4>, dim3(16, max_rem16, kNumXCD), dim3(256), 0, st, (const float *)slabs, fx_amax, binv, C, ldc,
                                    (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, np.a_raw, np.stats, np.dM, 0, y_amax, tiles_m, tiles_n);
             else
-                hipLaunchKernelGGL(nt_fixup_h2_kernel<1>, dim3(64, max_rem16, kNumXCD), dim3(256), 0, st, (const float *)slabs, (const float *)nullptr, binv, C, ldc,
+                hipLaunchKernelGGL(nt_fixup_h2_kernel<1>, dim3(64, max_rem16, kNumXCD), dim3(256), 0, st, (const float *)slabs, fx_amax, binv, C, ldc,
                                    (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, np.a_raw, np.stats, np.dM, 0, y_amax, tiles_m, tiles_n);
             rc16 = check_launch(what);
         }
@@ -256,26 +294,7 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
     if (M > INT32_MAX - BM || N > INT32_MAX - BN || K > INT32_MAX - BK) { set_error("%s: dimension too large", what); return TOAD_ESHAPE; }
     if (K % 4 != 0 || lda % 4 != 0 || ldb % 4 != 0) { set_error("%s: reduction dim %lld must be a multiple of 4", what, (long long)K); return TOAD_ESHAPE; }
     if (!aligned16(A) || !aligned16(B) || !aligned16(C)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_SMEM);
-        attr_set = true;
-    }
-    static int use_big = -1;
-    static float *slab_ws = nullptr;
-    if (use_big < 0) {
-        const char *e = getenv("TOAD_GEMM_BIG");           // A/B knob; default on
-        use_big = e ? atoi(e) : 1;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_f32_big_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM);
-    }
-    static int use_split = -1;
-    if (use_split < 0) {
-        const char *e = getenv("TOAD_GEMM_SPLIT");         // A/B knob
-        use_split = e ? atoi(e) : 1;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_split_big_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SP_SMEM);
-    }
+    const int use_big = cfg().big, use_split = cfg().split;
     if (use_big && use_split && !es.drop.thresh && !mask_src && ldb == K && (uint64_t)M * lda * 4 < (1ull << 32) &&
         narrow_ok(M, N, K, ldc, bias, addend, ws)) {
         const ConvGeom none{0, 0, 0, 0, 0, 0, 0, 0};
@@ -305,6 +324,7 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
         }
         return rc;
     }
+#ifdef TOAD_AB_KNOBS        // exact-fp32 persistent arm (TOAD_GEMM_SPLIT=0)
     if (use_big && ws && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && (uint64_t)M * lda * 4 < (1ull << 32) &&
         (uint64_t)N * ldb * 4 < (1ull << 32)) {
         const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
@@ -321,7 +341,7 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
         }
         return rc;
     }
-    (void)slab_ws;
+#endif
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     const int grid = kNumXCD * ((tiles_m + kNumXCD - 1) / kNumXCD) * tiles_n;
     hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3(grid), dim3(256), NT_SMEM, st, A, lda, B, ldb, C, ldc, (int)M, (int)N,
@@ -423,10 +443,8 @@ extern "C" int toad_linear_act_res_fwd_f32(const float *X, const float *W, const
     // Wide outputs (the extractor's 1x1 expansions / downsamples and its 256-channel 3x3 after im2col) run on the fp16 two-piece
     // kernel of the MIL path: 3 MFMA terms per product instead of the split-bf16 kernel's 6. X's abs-max array is measured in `ws`
     // (one read of X; the producers here are the narrow kernels, which do not emit it). Shapes the narrow tiles take (N <= 128,
-    // short-K residual GEMMs) keep them. TOAD_EXTRACT_H2=0: the round-1 dispatch.
-    static int ext_h2 = -1;
-    if (ext_h2 < 0) { const char *e = getenv("TOAD_EXTRACT_H2"); ext_h2 = e ? atoi(e) : 1; }
-    if (ext_h2 && h2_enabled() && ws && h2_nt_ok(M, N, K, K, N) && !narrow_ok(M, N, K, N, bias, residual, ws)) {
+    // short-K residual GEMMs) keep them.
+    if (cfg().ext_h2 && h2_enabled() && ws && h2_nt_ok(M, N, K, K, N) && !narrow_ok(M, N, K, N, bias, residual, ws)) {
         const H2Pool nopool{nullptr, nullptr, nullptr, 0};
         return launch_nt_auto(X, K, nullptr, W, K, Y, N, M, N, K, bias, es, residual, nullptr, nullptr, nopool, nullptr, nullptr, ws,
                               (hipStream_t)stream, what);
@@ -490,16 +508,7 @@ extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const flo
                           H2Pool{pool_a_raw, pool_stats, pool_dM, pool_T}, dx_amax, nullptr, ws, (hipStream_t)stream, what);
 }
 
-static bool tn_big_ok(int64_t M, int64_t N, int64_t K) {
-    static int use_big = -1;
-    if (use_big < 0) {
-        const char *e = getenv("TOAD_GEMM_BIG");           // A/B knob; default on
-        use_big = e ? atoi(e) : 1;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f32_big_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM);
-    }
-    return use_big && M >= 64 && N >= 4 && K >= 4;
-}
+static bool tn_big_ok(int64_t M, int64_t N, int64_t K) { return cfg().big && M >= 64 && N >= 4 && K >= 4; }
 
 extern "C" size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -512,8 +521,10 @@ extern "C" size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K) {
 
 // dW = beta*dW + dY^T X (+ db). dy_amax / x_amax: abs-max arrays of the operands (NULL -> measured here).
 int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, const float *x_amax, float *dW, float *db, int64_t M,
-                        int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what, bool x_half, WgradDeferred *defer) {
-    if (x_half && !(tn_big_ok(M, N, K) && h2_enabled())) { set_error("%s: an fp16 input operand needs the h2 wgrad kernel", what); return TOAD_ESHAPE; }
+                        int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what, int x_mode, WgradDeferred *defer) {
+    // x_mode: TOAD_X_F32 = fp32 [M][K]; TOAD_X_F16 = fp16 [M][K]; TOAD_X_PT = plane-tiled (gemm_pt.inc; x_amax = its per-row-tile abs-max)
+    if (x_mode != TOAD_X_F32 && !(tn_big_ok(M, N, K) && h2_enabled())) { set_error("%s: an fp16 / plane-tiled input operand needs the h2 wgrad kernels", what); return TOAD_ESHAPE; }
+    if (x_mode == TOAD_X_PT && !x_amax) { set_error("%s: a plane-tiled operand comes with its abs-max array", what); return TOAD_EINVAL; }
     float *slab = (float *)ws;
     int nsplit;
     int rc;
@@ -523,19 +534,15 @@ int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, co
         const TnPlan q = tn_plan(M, N, K);
         nsplit = q.nsplit;
         float *cs = db ? slab + (size_t)nsplit * N * K : nullptr;
-        static int tn_split = -1;
-        if (tn_split < 0) {
-            const char *e = getenv("TOAD_GEMM_SPLIT");     // A/B knob (exact-fp32 arm when 0 and TOAD_GEMM_H2=0)
-            tn_split = e ? atoi(e) : 1;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_split_big_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM);
-        }
         if (h2_enabled()) {
             h2 = true;
             scales = slab + (size_t)nsplit * (size_t)(N * K + N);
             float *amax_ws = scales + 16;
             if (!dy_amax) { if ((rc = launch_absmax(dY, N, M, N, amax_ws, true, st, what))) return rc; dy_amax = amax_ws; }
-            if (x_half) {
+            if (x_mode == TOAD_X_PT) {
+                hipLaunchKernelGGL(gemm_tn_pt_kernel, dim3(PB_GRID), dim3(512), TP_SMEM, st, dY, N, dy_amax, reinterpret_cast<const unsigned short *>(X),
+                                   x_amax, (int)pt_col_stages(K), slab, cs, scales, (int)M, (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
+            } else if (x_mode == TOAD_X_F16) {
                 hipLaunchKernelGGL(gemm_tn_h2_big_kernel<true>, dim3(PB_GRID), dim3(512), TN2_SMEM, st, dY, N, dy_amax, X, K, (const float *)nullptr, slab, cs,
                                    scales, (int)M, (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
             } else {
@@ -543,44 +550,17 @@ int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, co
                 hipLaunchKernelGGL(gemm_tn_h2_big_kernel<false>, dim3(PB_GRID), dim3(512), TN2_SMEM, st, dY, N, dy_amax, X, K, x_amax, slab, cs, scales,
                                    (int)M, (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
             }
-        } else if (tn_split)
+        }
+#ifdef TOAD_AB_KNOBS        // round 1's arms (TOAD_GEMM_H2=0): split-bf16, or exact fp32 with TOAD_GEMM_SPLIT=0
+        else if (cfg().split)
             hipLaunchKernelGGL(gemm_tn_split_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, X, K, slab, cs, (int)M,
                                (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
         else
             hipLaunchKernelGGL(gemm_tn_f32_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, X, K, slab, cs, (int)M,
                                (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
+#endif
         rc = check_launch(what);
-#ifdef TOAD_H2_TRACE
-        if (h2 && getenv("TOAD_TN_TRACE")) {                // tracing build: print the timing summary of this launch
-            static unsigned long long hb[2048];
-            (void)hipStreamSynchronize(st);
-            (void)hipMemcpyFromSymbol(hb, HIP_SYMBOL(g_tn_trace), sizeof(hb));
-            double cmin = 1e30, cmax = 0, csum = 0, rmin = 1e30, rmax = 0, r0 = 1e30, r1 = 0;
-            for (int b = 0; b < PB_GRID; ++b) {
-                const double c = (double)(hb[b * 4 + 1] - hb[b * 4]), r = (double)(hb[b * 4 + 3] - hb[b * 4 + 2]) / 100.0;
-                cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax; csum += c; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax;
-                r0 = (double)hb[b * 4 + 2] < r0 ? (double)hb[b * 4 + 2] : r0; r1 = (double)hb[b * 4 + 3] > r1 ? (double)hb[b * 4 + 3] : r1;
-            }
-            double per = 0; int np = 0;
-            for (int i = 1; i < 64; ++i) if (hb[1024 + i] > hb[1024 + i - 1]) { per += (double)(hb[1024 + i] - hb[1024 + i - 1]); ++np; }
-            fprintf(stderr, "[tn trace] %s M=%lld N=%lld K=%lld: workgroup cycles min %.0f mean %.0f max %.0f | us min %.1f max %.1f | first start -> last end %.1f us | "
-                    "step period %.0f cycles (%d samples) | epilogue of workgroup 0: %.0f cycles after step %llu\n", what, (long long)M, (long long)N, (long long)K,
-                    cmin, csum / PB_GRID, cmax, rmin, rmax, (r1 - r0) / 100.0, np ? per / np : 0.0, np, (double)(hb[1101] - hb[1100]), hb[1102]);
-#if TOAD_H2_TRACE == 1
-            for (int w = 0; w < 2; ++w) {               // phase means over steps 8..23: stage loads | k16 step 0 | k16 step 1 + staging | barrier | first fragment reads
-                double ph[5] = {0, 0, 0, 0, 0};
-                for (int i = 0; i < 16; ++i) { const unsigned long long *tr = hb + 1200 + (i * 2 + w) * 6; for (int k = 0; k < 5; ++k) ph[k] += (double)(tr[k + 1] - tr[k]) / 16.0; }
-                fprintf(stderr, "[tn trace]    wave %d: stage_load issue %.0f | k16 step 0 %.0f | k16 step 1 + staging %.0f | barrier %.0f | fragment reads %.0f\n", w ? 5 : 0, ph[0], ph[1], ph[2], ph[3], ph[4]);
-            }
-#endif
-        }
-#endif
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN_SMEM);
-            attr_set = true;
-        }
         const WgradPlan p = wgrad_plan(M, N, K);
         nsplit = p.nsplit;
         float *cs = db ? slab + (size_t)nsplit * N * K : nullptr;
@@ -635,6 +615,18 @@ extern "C" int toad_linear_wgrad_f32(const float *dY, const float *X, float *dW,
     if (!aligned16(dY) || !aligned16(X) || !aligned16(dW) || !aligned16(ws)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
     if (ws_bytes < toad_linear_wgrad_ws_bytes(M, N, K)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
     return launch_wgrad(dY, dy_amax, X, x_amax, dW, db, M, N, K, beta, ws, (hipStream_t)stream, what);
+}
+
+extern "C" int toad_linear_wgrad_xp_f32(const float *dY, const void *Xp, const float *x_amax, float *dW, float *db, int64_t M, int64_t N,
+                                         int64_t K, float beta, const float *dy_amax, void *ws, size_t ws_bytes, void *stream) {
+    const char *what = "toad_linear_wgrad_xp_f32";
+    if (!dY || !Xp || !x_amax || !dW || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (M <= 0 || N <= 0 || K <= 0) { set_error("%s: non-positive dimension", what); return TOAD_EINVAL; }
+    if (N % 4 != 0 || K % 8 != 0) { set_error("%s: N must be a multiple of 4, K of 8", what); return TOAD_ESHAPE; }
+    if (M > INT32_MAX - 4096) { set_error("%s: M too large", what); return TOAD_ESHAPE; }
+    if (!aligned16(dY) || !aligned16(Xp) || !aligned16(dW) || !aligned16(ws)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (ws_bytes < toad_linear_wgrad_ws_bytes(M, N, K)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
+    return launch_wgrad(dY, dy_amax, reinterpret_cast<const float *>(Xp), x_amax, dW, db, M, N, K, beta, ws, (hipStream_t)stream, what, TOAD_X_PT);
 }
 
 extern "C" int toad_transpose_f32(const float *in, float *out, int64_t rows, int64_t cols, void *stream) {

@@ -148,13 +148,14 @@ static DropSeeds drop_seeds(float drop_p, uint64_t seed) {          // must matc
 // forward up to the pooled features: trunk, stacked attention GEMM, fused gated pool. `ev` records bench events (or nothing).
 template <typename Ev>
 static int forward_body(const MilShape &s, const Params &p, const float *X, const float *x_amax, float drop_p, uint64_t seed,
-                        bool attention_only, const Fwd &f, const Scratch &w, hipStream_t st, Ev ev, const char *what, bool x_half,
+                        bool attention_only, const Fwd &f, const Scratch &w, hipStream_t st, Ev ev, const char *what, int x_mode,
                         bool with_backward_operands = false) {
     const int64_t N = s.N;
     const int D2 = 2 * s.D;
     const DropSeeds ds = drop_seeds(drop_p, seed);
     const bool h2 = h2_nt_ok(N, kL, kL0, kL0, kL);
-    if (x_half && !h2) { set_error("%s: an fp16 bag needs the fp16 two-piece kernels (N * 1024 * 4 < 2^32, TOAD_GEMM_H2 != 0)", what); return TOAD_ESHAPE; }
+    if (x_mode != TOAD_X_F32 && !h2) { set_error("%s: an fp16 / prepared bag needs the fp16 two-piece kernels (N * 1024 * 4 < 2^32)", what); return TOAD_ESHAPE; }
+    if (x_mode == TOAD_X_PT && !x_amax) { set_error("%s: a prepared bag comes with its abs-max array", what); return TOAD_EINVAL; }
     const EpiScalars relu1{1, 1.f, make_drop(drop_p, ds.s1)}, relu2{1, 1.f, make_drop(drop_p, ds.s2)}, lin{0, 1.f, make_drop(0.f, 0)};
     const H2Pool nopool{nullptr, nullptr, nullptr, 0};
     if (h2) {
@@ -174,10 +175,11 @@ static int forward_body(const MilShape &s, const Params &p, const float *X, cons
             TOAD_TRY(launch_split_h2(ops, 3, f.amax_x, nz, st, what));
         }
         // an fp16 bag needs no abs-max array: its elements are first pieces with scale 1 (gemm_nt_h2_big_kernel, A16)
-        if (x_half) {}
+        const float *ax = x_mode == TOAD_X_PT ? x_amax : f.amax_x;    // a prepared bag carries its own array: nothing to copy or measure
+        if (x_mode != TOAD_X_F32) {}
         else if (x_amax) (void)hipMemcpyAsync(f.amax_x, x_amax, toad_amax_floats(N) * sizeof(float), hipMemcpyDeviceToDevice, st);
         else TOAD_TRY(launch_absmax(X, kL0, N, kL0, f.amax_x, false, st, what));
-        ev(2); TOAD_TRY(launch_nt_h2(X, kL0, f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h1, f.bits_h1, st, what, x_half)); ev(3);
+        ev(2); TOAD_TRY(launch_nt_h2(X, kL0, ax, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h1, f.bits_h1, st, what, x_mode)); ev(3);
         ev(4); TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h, f.bits_h, st, what)); ev(5);
         ev(6); TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nullptr, nopool, w.slabs, nullptr, nullptr, st, what)); ev(7);
     } else {       // shapes beyond the persistent kernels' 32-bit offsets (> 1 M patches): the per-op entry points pick their kernels
@@ -195,14 +197,14 @@ static int forward_body(const MilShape &s, const Params &p, const float *X, cons
 
 // backward from dM (gradient of the pooled features) down to the trunk weights (and dX)
 template <typename Ev>
-static int backward_body(const MilShape &s, const Params &p, float *const *grads, float beta, const float *X, float drop_p, uint64_t seed,
+static int backward_body(const MilShape &s, const Params &p, float *const *grads, float beta, const float *X, const float *x_amax_pt, float drop_p, uint64_t seed,
                          const Fwd &f, const float *dM, const float *dA_ext, float *dX, const Scratch &w, hipStream_t st, Ev ev, const char *what,
-                         bool x_half, bool presplit = false) {
+                         int x_mode, bool presplit = false) {
     const int64_t N = s.N;
     const int D2 = 2 * s.D;
     const DropSeeds ds = drop_seeds(drop_p, seed);
     const bool h2 = h2_nt_ok(N, kL, kL0, kL0, kL);
-    if (x_half && !h2) { set_error("%s: an fp16 bag needs the fp16 two-piece kernels", what); return TOAD_ESHAPE; }
+    if (x_mode != TOAD_X_F32 && !h2) { set_error("%s: an fp16 / prepared bag needs the fp16 two-piece kernels", what); return TOAD_ESHAPE; }
     const EpiScalars msk{0, ds.mscale, make_drop(0.f, 0)}, plain{0, 1.f, make_drop(0.f, 0)};
     const H2Pool nopool{nullptr, nullptr, nullptr, 0};
     if (h2) {
@@ -216,14 +218,14 @@ static int backward_body(const MilShape &s, const Params &p, float *const *grads
         TOAD_TRY(launch_pool_bwd(f.P, f.P + s.D, D2, f.H, p.wc, f.A_raw, f.stats, f.M, dM, dA_ext, w.dP, w.dP + s.D, D2, nullptr,
                                  grads[6], grads[7], beta, w.amax_dP, false, w.poolb_ws, w.poolb_ws_bytes, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st));
         WgradDeferred dw[3];
-        ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what, false, &dw[0])); ev(9);
+        ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what, TOAD_X_F32, &dw[0])); ev(9);
         // dZ2 = (dP Wab + dH_pool) * (H > 0): the pooling gradient dH_pool is recomputed in the epilogue from A_raw, stats, dM
         ev(10); TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, nullptr, f.H, f.bits_h,
                                       H2Pool{f.A_raw, f.stats, dM, kT}, w.slabs, w.amax_dZ2, nullptr, st, what)); ev(11);
-        ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws2, st, what, false, &dw[1])); ev(13);
+        ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws2, st, what, TOAD_X_F32, &dw[1])); ev(13);
         ev(14); TOAD_TRY(launch_nt_h2(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, f.bits_h1, nopool,
                                       w.slabs, w.amax_dZ1, nullptr, st, what)); ev(15);
-        ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, X, f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws3, st, what, x_half, &dw[2]));
+        ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, X, x_mode == TOAD_X_PT ? x_amax_pt : f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws3, st, what, x_mode, &dw[2]));
         TOAD_TRY(launch_wgrad_reduce(dw, 3, st, what)); ev(17);
         if (dX) TOAD_TRY(launch_nt_h2(w.dZ1, kL, w.amax_dZ1, w.planes[W_1T], w.binv[W_1T], dX, kL0, N, kL0, kL, nullptr, plain, nullptr, nullptr, nullptr, nopool,
                                       w.slabs, nullptr, nullptr, st, what));
@@ -290,7 +292,7 @@ static char *align_base(void *p, int64_t N) {
 
 static int mil_fwd_impl(const float *const *params, const float *X, const float *sex, int64_t N, int C, int D, float drop_p,
                         uint64_t seed, const float *x_amax, int attention_only, void *arena, size_t arena_bytes,
-                        void *scratch, size_t scratch_bytes, void *stream, bool x_half, const char *what) {
+                        void *scratch, size_t scratch_bytes, void *stream, int x_mode, const char *what) {
     const MilShape s{N, C, D};
     if (!params || !X || !arena || !scratch || (!attention_only && !sex)) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (!shape_ok(s)) { set_error("%s: unsupported shape N=%lld C=%d D=%d", what, (long long)N, C, D); return TOAD_ESHAPE; }
@@ -305,7 +307,7 @@ static int mil_fwd_impl(const float *const *params, const float *X, const float 
     if (!load_params(params, p, what)) return TOAD_EINVAL;
     const Fwd f = arena_view(s, ab);
     hipStream_t st = (hipStream_t)stream;
-    TOAD_TRY(forward_body(s, p, X, x_amax, drop_p, seed, attention_only != 0, f, w, st, NoEvents{}, what, x_half));
+    TOAD_TRY(forward_body(s, p, X, x_amax, drop_p, seed, attention_only != 0, f, w, st, NoEvents{}, what, x_mode));
     if (attention_only) return TOAD_OK;
     return toad_heads_fwd_f32(f.M, sex, p.wcls, p.bcls, p.wsite, p.bsite, f.Mcat, f.logits, f.yprob, f.yhat, f.slog, f.sprob, f.shat, kL, C, st);
 }
@@ -313,20 +315,20 @@ static int mil_fwd_impl(const float *const *params, const float *X, const float 
 extern "C" int toad_mil_fwd_f32(const float *const *params, const float *X, const float *sex, int64_t N, int C, int D, float drop_p,
                                  uint64_t seed, const float *x_amax, int attention_only, void *arena, size_t arena_bytes,
                                  void *scratch, size_t scratch_bytes, void *stream) {
-    return mil_fwd_impl(params, X, sex, N, C, D, drop_p, seed, x_amax, attention_only, arena, arena_bytes, scratch, scratch_bytes, stream, false,
+    return mil_fwd_impl(params, X, sex, N, C, D, drop_p, seed, x_amax, attention_only, arena, arena_bytes, scratch, scratch_bytes, stream, TOAD_X_F32,
                         "toad_mil_fwd_f32");
 }
 extern "C" int toad_mil_fwd_x16_f32(const float *const *params, const void *X16, const float *sex, int64_t N, int C, int D, float drop_p,
                                      uint64_t seed, int attention_only, void *arena, size_t arena_bytes, void *scratch, size_t scratch_bytes,
                                      void *stream) {
     return mil_fwd_impl(params, reinterpret_cast<const float *>(X16), sex, N, C, D, drop_p, seed, nullptr, attention_only, arena, arena_bytes, scratch,
-                        scratch_bytes, stream, true, "toad_mil_fwd_x16_f32");
+                        scratch_bytes, stream, TOAD_X_F16, "toad_mil_fwd_x16_f32");
 }
 
-static int mil_bwd_impl(const float *const *params, float *const *grads, float beta, const float *X, int64_t N, int C, int D,
+static int mil_bwd_impl(const float *const *params, float *const *grads, float beta, const float *X, const float *x_amax_pt, int64_t N, int C, int D,
                         float drop_p, uint64_t seed, const void *arena, size_t arena_bytes, const float *dlogits,
                         const float *dsite, const float *dA_ext, const float *dMcat_ext, float *dX, float *dsex,
-                        void *scratch, size_t scratch_bytes, void *stream, bool x_half, const char *what) {
+                        void *scratch, size_t scratch_bytes, void *stream, int x_mode, const char *what) {
     const MilShape s{N, C, D};
     if (!params || !grads || !X || !arena || !scratch || !dlogits || !dsite) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (!shape_ok(s)) { set_error("%s: unsupported shape N=%lld C=%d D=%d", what, (long long)N, C, D); return TOAD_ESHAPE; }
@@ -342,22 +344,22 @@ static int mil_bwd_impl(const float *const *params, float *const *grads, float b
     const Fwd f = arena_view(s, ab);
     hipStream_t st = (hipStream_t)stream;
     TOAD_TRY(toad_heads_bwd_f32(f.Mcat, dlogits, dsite, p.wcls, p.wsite, dMcat_ext, grads[8], grads[9], grads[10], grads[11], w.dM, dsex, beta, kL, C, st));
-    return backward_body(s, p, grads, beta, X, drop_p, seed, f, w.dM, dA_ext, dX, w, st, NoEvents{}, what, x_half);
+    return backward_body(s, p, grads, beta, X, x_amax_pt, drop_p, seed, f, w.dM, dA_ext, dX, w, st, NoEvents{}, what, x_mode);
 }
 
 extern "C" int toad_mil_bwd_f32(const float *const *params, float *const *grads, float beta, const float *X, int64_t N, int C, int D,
                                  float drop_p, uint64_t seed, const void *arena, size_t arena_bytes, const float *dlogits,
                                  const float *dsite, const float *dA_ext, const float *dMcat_ext, float *dX, float *dsex,
                                  void *scratch, size_t scratch_bytes, void *stream) {
-    return mil_bwd_impl(params, grads, beta, X, N, C, D, drop_p, seed, arena, arena_bytes, dlogits, dsite, dA_ext, dMcat_ext, dX, dsex, scratch,
-                        scratch_bytes, stream, false, "toad_mil_bwd_f32");
+    return mil_bwd_impl(params, grads, beta, X, nullptr, N, C, D, drop_p, seed, arena, arena_bytes, dlogits, dsite, dA_ext, dMcat_ext, dX, dsex, scratch,
+                        scratch_bytes, stream, TOAD_X_F32, "toad_mil_bwd_f32");
 }
 extern "C" int toad_mil_bwd_x16_f32(const float *const *params, float *const *grads, float beta, const void *X16, int64_t N, int C, int D,
                                      float drop_p, uint64_t seed, const void *arena, size_t arena_bytes, const float *dlogits,
                                      const float *dsite, const float *dA_ext, const float *dMcat_ext, float *dsex,
                                      void *scratch, size_t scratch_bytes, void *stream) {
-    return mil_bwd_impl(params, grads, beta, reinterpret_cast<const float *>(X16), N, C, D, drop_p, seed, arena, arena_bytes, dlogits, dsite, dA_ext,
-                        dMcat_ext, nullptr, dsex, scratch, scratch_bytes, stream, true, "toad_mil_bwd_x16_f32");
+    return mil_bwd_impl(params, grads, beta, reinterpret_cast<const float *>(X16), nullptr, N, C, D, drop_p, seed, arena, arena_bytes, dlogits, dsite, dA_ext,
+                        dMcat_ext, nullptr, dsex, scratch, scratch_bytes, stream, TOAD_X_F16, "toad_mil_bwd_x16_f32");
 }
 
 // events: NULL, or 18 hipEvent_t: [0,1] bracket the fused pool forward, [2+2i, 3+2i] bracket GEMM call i
@@ -366,7 +368,7 @@ static int mil_step_impl(const float *const *params, float *const *grads, float 
                          const float *sex, const int64_t *label, const int64_t *site, float w_cls,
                          float w_site, int64_t N, int C, int D, float drop_p, uint64_t seed, const float *x_amax,
                          float *loss_out, float *logits_out, float *site_logits_out, void *ws,
-                         size_t ws_bytes, void **events, void *stream, bool x_half, const char *what) {
+                         size_t ws_bytes, void **events, void *stream, int x_mode, const char *what) {
     const MilShape s{N, C, D};
     if (!params || !grads || !X || !sex || !label || !site || !loss_out || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (!shape_ok(s)) { set_error("%s: unsupported shape N=%lld C=%d D=%d", what, (long long)N, C, D); return TOAD_ESHAPE; }
@@ -384,13 +386,13 @@ static int mil_step_impl(const float *const *params, float *const *grads, float 
     hipStream_t st = (hipStream_t)stream;
     const StreamEvents ev{events, st};
     const bool presplit = h2_nt_ok(N, kL, kL0, kL0, kL);
-    TOAD_TRY(forward_body(s, p, X, x_amax, drop_p, seed, false, f, w, st, ev, what, x_half, presplit));
+    TOAD_TRY(forward_body(s, p, X, x_amax, drop_p, seed, false, f, w, st, ev, what, x_mode, presplit));
     // heads + weighted CE + heads backward: one single-workgroup launch
     TOAD_TRY(toad_heads_ce_fused_f32(f.M, sex, p.wcls, p.bcls, p.wsite, p.bsite, label, site, w_cls, w_site, f.Mcat, f.logits, f.yprob, f.yhat,
                                      f.slog, f.sprob, f.shat, loss_out, nullptr, nullptr, grads[8], grads[9], grads[10], grads[11], w.dM, beta, kL, C, st));
     if (logits_out) (void)hipMemcpyAsync(logits_out, f.logits, C * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (site_logits_out) (void)hipMemcpyAsync(site_logits_out, f.slog, 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
-    return backward_body(s, p, grads, beta, X, drop_p, seed, f, w.dM, nullptr, nullptr, w, st, ev, what, x_half, presplit);
+    return backward_body(s, p, grads, beta, X, x_amax, drop_p, seed, f, w.dM, nullptr, nullptr, w, st, ev, what, x_mode, presplit);
 }
 extern "C" int toad_mil_step_f32(const float *const *params, float *const *grads, float beta, const float *X,
                                   const float *sex, const int64_t *label, const int64_t *site, float w_cls,
@@ -398,7 +400,7 @@ extern "C" int toad_mil_step_f32(const float *const *params, float *const *grads
                                   float *loss_out, float *logits_out, float *site_logits_out, void *ws,
                                   size_t ws_bytes, void **events, void *stream) {
     return mil_step_impl(params, grads, beta, X, sex, label, site, w_cls, w_site, N, C, D, drop_p, seed, x_amax, loss_out, logits_out,
-                         site_logits_out, ws, ws_bytes, events, stream, false, "toad_mil_step_f32");
+                         site_logits_out, ws, ws_bytes, events, stream, TOAD_X_F32, "toad_mil_step_f32");
 }
 extern "C" int toad_mil_step_x16_f32(const float *const *params, float *const *grads, float beta, const void *X16,
                                       const float *sex, const int64_t *label, const int64_t *site, float w_cls,
@@ -406,5 +408,44 @@ extern "C" int toad_mil_step_x16_f32(const float *const *params, float *const *g
                                       float *loss_out, float *logits_out, float *site_logits_out, void *ws,
                                       size_t ws_bytes, void **events, void *stream) {
     return mil_step_impl(params, grads, beta, reinterpret_cast<const float *>(X16), sex, label, site, w_cls, w_site, N, C, D, drop_p, seed, nullptr,
-                         loss_out, logits_out, site_logits_out, ws, ws_bytes, events, stream, true, "toad_mil_step_x16_f32");
+                         loss_out, logits_out, site_logits_out, ws, ws_bytes, events, stream, TOAD_X_F16, "toad_mil_step_x16_f32");
+}
+
+// ---- prepared bags (ABI 9) --------------------------------------------------------------------------------------------
+// The bag of a slide is constant across epochs, and the two GEMMs that read it (the first Linear, models/model_toad.py:59, and its
+// weight gradient) are a third of the step's flops. toad_bag_prepare_f32 converts it ONCE - at ingest, next to the host-to-device
+// copy - into the plane-tiled two-piece form those GEMMs consume by LDS-DMA without any conversion (csrc/gemm_pt.inc): the same
+// 4 bytes per element as fp32, so the caller may drop the fp32 copy. `amax` receives the bag's abs-max array (toad_amax_floats(N)
+// floats), which the *_xp_* calls take back together with the planes.
+extern "C" size_t toad_bag_planes_bytes(int64_t N, int64_t K) { return (N > 0 && K > 0) ? pt_bytes_host(N, K) : 0; }
+extern "C" int toad_bag_prepare_f32(const float *X, int64_t N, int64_t K, void *planes, float *amax, void *stream) {
+    const char *what = "toad_bag_prepare_f32";
+    if (!X || !planes || !amax || N <= 0 || K <= 0 || K % 8 != 0) { set_error("%s: bad argument (K must be a multiple of 8)", what); return TOAD_EINVAL; }
+    if (N > INT32_MAX - 4096) { set_error("%s: N too large", what); return TOAD_ESHAPE; }
+    if (!aligned16(X) || !aligned16(planes)) { set_error("%s: X and planes must be 16-byte aligned", what); return TOAD_EALIGN; }
+    hipStream_t st = (hipStream_t)stream;
+    TOAD_TRY(launch_absmax(X, K, N, K, amax, true, st, what));
+    return launch_pt_split(X, K, N, K, amax, reinterpret_cast<unsigned short *>(planes), st, what);
+}
+extern "C" int toad_mil_fwd_xp_f32(const float *const *params, const void *Xp, const float *x_amax, const float *sex, int64_t N, int C, int D,
+                                    float drop_p, uint64_t seed, int attention_only, void *arena, size_t arena_bytes, void *scratch,
+                                    size_t scratch_bytes, void *stream) {
+    return mil_fwd_impl(params, reinterpret_cast<const float *>(Xp), sex, N, C, D, drop_p, seed, x_amax, attention_only, arena, arena_bytes, scratch,
+                        scratch_bytes, stream, TOAD_X_PT, "toad_mil_fwd_xp_f32");
+}
+extern "C" int toad_mil_bwd_xp_f32(const float *const *params, float *const *grads, float beta, const void *Xp, const float *x_amax, int64_t N, int C,
+                                    int D, float drop_p, uint64_t seed, const void *arena, size_t arena_bytes, const float *dlogits,
+                                    const float *dsite, const float *dA_ext, const float *dMcat_ext, float *dsex, void *scratch,
+                                    size_t scratch_bytes, void *stream) {
+    if (!x_amax) { set_error("toad_mil_bwd_xp_f32: null x_amax"); return TOAD_EINVAL; }
+    return mil_bwd_impl(params, grads, beta, reinterpret_cast<const float *>(Xp), x_amax, N, C, D, drop_p, seed, arena, arena_bytes, dlogits, dsite, dA_ext,
+                        dMcat_ext, nullptr, dsex, scratch, scratch_bytes, stream, TOAD_X_PT, "toad_mil_bwd_xp_f32");
+}
+extern "C" int toad_mil_step_xp_f32(const float *const *params, float *const *grads, float beta, const void *Xp, const float *x_amax,
+                                     const float *sex, const int64_t *label, const int64_t *site, float w_cls, float w_site, int64_t N,
+                                     int C, int D, float drop_p, uint64_t seed, float *loss_out, float *logits_out,
+                                     float *site_logits_out, void *ws, size_t ws_bytes, void **events, void *stream) {
+    if (!x_amax) { set_error("toad_mil_step_xp_f32: null x_amax"); return TOAD_EINVAL; }
+    return mil_step_impl(params, grads, beta, reinterpret_cast<const float *>(Xp), sex, label, site, w_cls, w_site, N, C, D, drop_p, seed, x_amax,
+                         loss_out, logits_out, site_logits_out, ws, ws_bytes, events, stream, TOAD_X_PT, "toad_mil_step_xp_f32");
 }

@@ -68,11 +68,16 @@ def hip_slide_grad(model, grads: Dict[str, torch.Tensor], slide: Slide, beta: fl
 
 class SlideShardedDP:
     def __init__(self, model, optimizer_factory: Callable[[Sequence[torch.nn.Parameter]], torch.optim.Optimizer],
-                 process_group=None, slide_grad_fn: Optional[Callable] = None, broadcast_from: int = 0):
+                 process_group=None, slide_grad_fn: Optional[Callable] = None, broadcast_from: int = 0,
+                 always_reduce: bool = False):
+        """``always_reduce``: issue the gradient all-reduce whenever a process group exists, also at world size 1 (a sum over one
+        rank: the values do not change, but the RCCL communicator and its kernel run on the launch stream exactly as they do at
+        N > 1 - the single-GPU proof of the collective path, tests/test_gpu_nccl_world1.py and bench.py's allreduce_us)."""
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.always_reduce = bool(always_reduce) and dist.is_initialized()
         self.flat = model.flat_parameters()
         if self.world > 1:                      # identical replicas: one broadcast at construction, never again
             dist.broadcast(self.flat, src=broadcast_from, group=process_group)
@@ -135,7 +140,9 @@ class SlideShardedDP:
                 for i, s in enumerate(slides)]
 
     def reduce(self):
-        if self.world > 1:
+        """ONE all-reduce(SUM) of the flat 4.77 MB gradient bucket, enqueued on the current stream behind the last slide's backward
+        (RCCL orders it after the kernels that wrote the bucket; the optimiser launch that follows is ordered after it)."""
+        if self.world > 1 or self.always_reduce:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
 
     def step(self, slides: Sequence[Slide], global_slides: int):

@@ -233,6 +233,10 @@ class TOAD_fc_mtl_concat(nn.Module):
         """fp32 bags pass; fp16 bags (feature stores kept in half precision) go to the kernels as they are when the whole-slide
         fp16 entry points take the shape (toad_mil_*_x16_f32: same results as the up-cast bag, two MFMA terms instead of three in the
         first layer); everything else (bf16, fp64, empty or oversized fp16 bags) is up-cast to fp32 like nn.Linear's caller would."""
+        if getattr(h, "is_prepared_bag", False):                   # ops.prepare_bag: already in the form the first GEMMs consume
+            if h.shape[1] != 1024 or not ops.x16_ok(h.shape[0]):
+                raise ValueError("a PreparedBag must be [N, 1024] with 64 <= N and N * 4096 < 2^32")
+            return h
         if h.dtype == torch.float32:
             return h
         if h.dtype == torch.float16 and h.dim() == 2 and h.shape[1] == 1024 and not h.requires_grad and ops.x16_ok(h.shape[0]):
@@ -279,6 +283,8 @@ class TOAD_fc_mtl_concat(nn.Module):
         256-row block of the CONCATENATED operand, so the values agree with the one-slide path to fp32 round-off, not bitwise."""
         if self.training and self._dropout:
             raise RuntimeError("forward_many is an inference path: call model.eval() first (dropout would be skipped)")
+        if any(getattr(b, "is_prepared_bag", False) for b in bags):
+            raise TypeError("forward_many concatenates fp32 bags; pass the tensors, not PreparedBag objects")
         bags = [b.contiguous() if b.dtype == torch.float32 else b.float().contiguous() for b in bags]   # (the per-op GEMMs of this path are fp32-only)
         if len(bags) != len(sexes):
             raise ValueError("forward_many: one sex entry per bag")

@@ -211,8 +211,12 @@ def linear_dgrad(dy, wt, addend=None, relu_src=None, out: Optional[torch.Tensor]
 def linear_wgrad(dy, x, dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None,
                  beta: float = 0.0, want_db: bool = True, dy_amax: Optional[torch.Tensor] = None,
                  x_amax: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """dW = beta*dW + dY^T X; db = beta*db + colsum(dY). dy_amax / x_amax: abs-max arrays of the operands (else measured)."""
-    _chk(dy, "dy"); _chk(x, "x"); _chk(dy_amax, "dy_amax", allow_none=True); _chk(x_amax, "x_amax", allow_none=True)
+    """dW = beta*dW + dY^T X; db = beta*db + colsum(dY). dy_amax / x_amax: abs-max arrays of the operands (else measured).
+    ``x`` may be a PreparedBag (plane-tiled input operand: toad_linear_wgrad_xp_f32)."""
+    prepared = getattr(x, "is_prepared_bag", False)
+    _chk(dy, "dy"); _chk(dy_amax, "dy_amax", allow_none=True)
+    if not prepared:
+        _chk(x, "x"); _chk(x_amax, "x_amax", allow_none=True)
     m, n = dy.shape
     m2, k = x.shape
     if m != m2:
@@ -226,8 +230,12 @@ def linear_wgrad(dy, x, dw: Optional[torch.Tensor] = None, db: Optional[torch.Te
     nbytes = lib.toad_linear_wgrad_ws_bytes(m, n, k)
     ws = _ws(nbytes, dy.device, "wgrad")
     with _timed("gemm_wgrad"):
-        _lib.check(lib.toad_linear_wgrad_f32(_p(dy), _p(x), _p(dw), _p(db), m, n, k, float(beta), _p(dy_amax), _p(x_amax),
-                                             _p(ws), ws.numel(), _stream()), "toad_linear_wgrad_f32")
+        if prepared:
+            _lib.check(lib.toad_linear_wgrad_xp_f32(_p(dy), _p(x.planes), _p(x.amax), _p(dw), _p(db), m, n, k, float(beta), _p(dy_amax),
+                                                    _p(ws), ws.numel(), _stream()), "toad_linear_wgrad_xp_f32")
+        else:
+            _lib.check(lib.toad_linear_wgrad_f32(_p(dy), _p(x), _p(dw), _p(db), m, n, k, float(beta), _p(dy_amax), _p(x_amax),
+                                                 _p(ws), ws.numel(), _stream()), "toad_linear_wgrad_f32")
     return dw, db
 
 
@@ -377,13 +385,63 @@ def _ptr_array(tensors):
     return arr
 
 
-def _chk_bag(bag: torch.Tensor) -> bool:
-    """The bag of a whole-slide call: fp32, or fp16 (features stored in half precision: toad_mil_*_x16_f32). -> is_half"""
+class PreparedBag:
+    """A slide's bag in the form the first Linear and its weight gradient consume directly (toad_bag_prepare_f32, ABI 9): the two
+    fp16 pieces of every element, plane-tiled in the GEMMs' LDS stage order, plus the bag's abs-max array. Same 4 bytes per
+    element as the fp32 bag it was made from (which the caller may drop). Made once per slide - at ingest - because a bag is an
+    input that stays the same across epochs (datasets/dataset_mtl_concat.py:369-373). Quacks like the [N, 1024] tensor it stands
+    for where the host code only asks for shape / device; it is not differentiable."""
+
+    is_prepared_bag = True
+    requires_grad = False
+    is_cuda = True
+    dtype = torch.float32            # the values it represents (fp32 precision)
+
+    def __init__(self, planes: torch.Tensor, amax: torch.Tensor, n: int, k: int):
+        self.planes, self.amax, self.shape = planes, amax, torch.Size((n, k))
+
+    @property
+    def device(self):
+        return self.planes.device
+
+    def dim(self) -> int:
+        return 2
+
+    def contiguous(self):
+        return self
+
+    def nbytes(self) -> int:
+        return self.planes.numel() + 4 * self.amax.numel()
+
+
+def prepare_bag(x: torch.Tensor) -> PreparedBag:
+    """fp32 (or fp16 / bf16: up-cast first) bag [N, K] on the device -> PreparedBag. One pass for the abs-max array, one for the
+    split (reads the bag twice, writes it once: ~0.2 ms per 100,000 x 1024 bag, off the training stream when done at ingest)."""
+    if x.dtype != torch.float32:
+        x = x.float()
+    x = x.contiguous()
+    _chk(x, "bag")
+    n, k = x.shape
+    if n == 0 or k % 8 != 0:
+        raise ValueError("prepare_bag: needs a non-empty [N, K] bag with K a multiple of 8")
+    lib = _lib.load()
+    planes = torch.empty(int(lib.toad_bag_planes_bytes(n, k)), dtype=torch.uint8, device=x.device)
+    amax = torch.empty(amax_floats(n), dtype=torch.float32, device=x.device)
+    _lib.check(lib.toad_bag_prepare_f32(_p(x), n, k, _p(planes), _p(amax), _stream()), "toad_bag_prepare_f32")
+    return PreparedBag(planes, amax, n, k)
+
+
+def _chk_bag(bag) -> int:
+    """The bag of a whole-slide call: fp32 (-> 0), fp16 (features stored in half precision: toad_mil_*_x16_f32, -> 1) or a
+    PreparedBag (toad_mil_*_xp_f32, -> 2)."""
+    if getattr(bag, "is_prepared_bag", False):
+        _chk(bag.planes, "bag planes", dtype=torch.uint8); _chk(bag.amax, "bag amax")
+        return 2
     if bag.dtype == torch.float16:
         _chk(bag, "bag", dtype=torch.float16)
-        return True
+        return 1
     _chk(bag, "bag")
-    return False
+    return 0
 
 
 def _step_dims(w, bag):
@@ -421,7 +479,11 @@ def mil_step(w, grads, beta: float, bag, sex, label, site, w_cls: float = 0.75, 
         nev = 18 if _TIMING_LEVEL >= 2 else 2
         ev_objs = [_take_event() for _ in range(nev)]
         events = (ctypes.c_void_p * 18)(*([e.cuda_event for e in ev_objs] + [None] * (18 - nev)))
-    if half:
+    if half == 2:
+        _lib.check(lib.toad_mil_step_xp_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag.planes), _p(bag.amax), _p(sex), _p(label),
+                                            _p(site), float(w_cls), float(w_site), n, c, d, float(drop_p), int(seed), _p(loss), _p(logits),
+                                            _p(slog), _p(ws), ws.numel(), events, _stream()), "toad_mil_step_xp_f32")
+    elif half:
         _lib.check(lib.toad_mil_step_x16_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag), _p(sex), _p(label), _p(site),
                                              float(w_cls), float(w_site), n, c, d, float(drop_p), int(seed), _p(loss), _p(logits),
                                              _p(slog), _p(ws), ws.numel(), events, _stream()), "toad_mil_step_x16_f32")
@@ -477,7 +539,11 @@ def mil_fwd(w, bag, sex, drop_p: float = 0.0, seed: int = 0, attention_only: boo
     arena = MilArena(n, c, d, bag.device)
     scratch = _ws(lib.toad_mil_scratch_bytes(n, c, d), bag.device, "mil")
     with _timed("mil_fwd"):
-        if half:
+        if half == 2:
+            _lib.check(lib.toad_mil_fwd_xp_f32(_ptr_array(ws_t), _p(bag.planes), _p(bag.amax), _p(sex), n, c, d, float(drop_p), int(seed),
+                                               1 if attention_only else 0, _p(arena.buf), arena.buf.numel(), _p(scratch), scratch.numel(),
+                                               _stream()), "toad_mil_fwd_xp_f32")
+        elif half:
             _lib.check(lib.toad_mil_fwd_x16_f32(_ptr_array(ws_t), _p(bag), _p(sex), n, c, d, float(drop_p), int(seed),
                                                 1 if attention_only else 0, _p(arena.buf), arena.buf.numel(), _p(scratch), scratch.numel(),
                                                 _stream()), "toad_mil_fwd_x16_f32")
@@ -493,7 +559,7 @@ def mil_bwd(w, grads, beta: float, bag, arena: MilArena, dlogits, dsite, da_ext=
     """Backward of mil_fwd in ONE library call: grads[slot] = beta*grads[slot] + gradient. Returns (dX | None, dsex | None)."""
     half = _chk_bag(bag)
     if half and need_dx:
-        raise ValueError("mil_bwd: no gradient with respect to an fp16 bag (up-cast it to float32 if the bag itself is trained)")
+        raise ValueError("mil_bwd: no gradient with respect to an fp16 / prepared bag (pass the float32 bag if the bag itself is trained)")
     _chk(dlogits, "dlogits"); _chk(dsite, "dsite")
     _chk(da_ext, "da_ext", allow_none=True); _chk(dmcat_ext, "dmcat_ext", allow_none=True)
     ws_t = [w[k] for k in STEP_SLOTS]
@@ -514,7 +580,11 @@ def mil_bwd(w, grads, beta: float, bag, arena: MilArena, dlogits, dsite, da_ext=
     scratch = _ws(lib.toad_mil_scratch_bytes(n, c, d), dev, "mil")
     buf = arena.buf
     with _timed("mil_bwd"):
-        if half:
+        if half == 2:
+            _lib.check(lib.toad_mil_bwd_xp_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag.planes), _p(bag.amax), n, c, d, float(drop_p),
+                                               int(seed), _p(buf), buf.numel(), _p(dlogits), _p(dsite), _p(da_ext), _p(dmcat_ext), _p(dsex),
+                                               _p(scratch), scratch.numel(), _stream()), "toad_mil_bwd_xp_f32")
+        elif half:
             _lib.check(lib.toad_mil_bwd_x16_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(bag), n, c, d, float(drop_p), int(seed),
                                                 _p(buf), buf.numel(), _p(dlogits), _p(dsite), _p(da_ext), _p(dmcat_ext), _p(dsex),
                                                 _p(scratch), scratch.numel(), _stream()), "toad_mil_bwd_x16_f32")

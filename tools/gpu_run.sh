@@ -1,0 +1,38 @@
+#!/bin/bash
+# One parameterised GPU job for `gpurun`: gpu_run.sh TAG [what ...]; results under gpurun_out/TAG/.
+#   tests[:expr]  pytest -m gpu (optionally -k expr or a file list after ':')      bench[:args]  bench.py (no CPU baseline unless args say so)
+#   ab:N          tools/ab_step.py on prepared and fp32 bags                         stats[:N]     rocprofv3 --kernel-trace --stats of the fused step
+#   pmc[:N]       SQ counter pass of the fused step                                  smoke         __graft_entry__.smoke()
+set -u
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-run}; shift
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+export TMPDIR=/tmp
+for what in "$@"; do
+  key=${what%%:*}; arg=""; [[ "$what" == *:* ]] && arg=${what#*:}
+  case $key in
+    tests)
+      if [ -z "$arg" ]; then timeout 900 python -m pytest tests -x -q -m gpu > $OUT/pytest.log 2>&1
+      elif [[ "$arg" == tests/* ]]; then timeout 900 python -m pytest $arg -x -q -m gpu > $OUT/pytest.log 2>&1
+      else timeout 900 python -m pytest tests -x -q -m gpu -k "$arg" > $OUT/pytest.log 2>&1; fi
+      echo "rc=$?" >> $OUT/pytest.log; tail -15 $OUT/pytest.log ;;
+    bench)
+      timeout 600 python bench.py ${arg:---steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 3} > $OUT/bench.json 2> $OUT/bench.err
+      tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
+    ab)
+      for r in 1 2; do for b in prepared fp32; do TOAD_BAG=$b timeout 300 python tools/ab_step.py ${arg:-100000} 30; done; done 2>&1 | grep -v amdgpu.ids | tee $OUT/ab.txt ;;
+    stats)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python $ROOT/tools/pmc_step.py ${arg:-100000} 8 > $OUT/prof.log 2>&1)
+      python tools/summarize_rocprof.py $(find $OUT/prof -name "*kernel_stats.csv" | head -1) "$TAG fused step N=${arg:-100000} (8 steps, prepared bag)" > $OUT/kernel_stats.md 2>&1
+      head -24 $OUT/kernel_stats.md ;;
+    pmc)
+      (cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE \
+          --kernel-trace --output-format csv -d $OUT/pmc -o p -- python $ROOT/tools/pmc_step.py ${arg:-100000} 3 > $OUT/pmc.log 2>&1)
+      python tools/pmc_table.py $(dirname $(find $OUT/pmc -name "*counter_collection.csv" | head -1)) > $OUT/pmc_step.txt 2>&1; head -30 $OUT/pmc_step.txt ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
+    *) echo "unknown job $what" ;;
+  esac
+done
