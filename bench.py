@@ -184,13 +184,35 @@ def cpu_baseline_pool(n_patches: int, budget_s: float = 20.0):
 
 
 BAG_DTYPE = torch.float32          # --bag-dtype fp16: bags stored in half precision (a side experiment, never the headline)
+BAG_PREPARED = True                # --bag-format prepared: the ingest format (toad_bag_prepare_f32); fp32: the raw tensor
 
 
-def make_slide(idx: int, n: int, dev):
-    """SURVEY.md 8(d) synthetic inputs: N(0,1) bag seeded by the slide index, generated on the device."""
+def make_slide(idx: int, n: int, dev, prepared=None):
+    """SURVEY.md 8(d) synthetic inputs: N(0,1) fp32 bag seeded by the slide index, generated on the device. With `prepared` it is
+    then brought into the resident ingest format (ops.prepare_bag: the two fp16 pieces of every fp32 element, plane-tiled; same
+    4 bytes per element, same values to 2^-22) and the fp32 tensor is dropped - what toad_amd.ingest does once per slide."""
     g = torch.Generator(device=dev).manual_seed(1000 + idx)
     bag = torch.randn(n, L0, device=dev, generator=g).to(BAG_DTYPE)
+    if (BAG_PREPARED if prepared is None else prepared) and BAG_DTYPE == torch.float32 and n >= 64:
+        from toad_amd import ops
+        bag = ops.prepare_bag(bag)
     return (bag, torch.tensor([float((idx // 2) % 2)], device=dev), torch.tensor([idx % C], device=dev), torch.tensor([idx % 2], device=dev))
+
+
+def time_prepare(n: int, dev, reps: int = 5):
+    """HIP-event time of ops.prepare_bag on one resident fp32 bag (abs-max pass + split pass): the one-off ingest cost per slide."""
+    from toad_amd import ops
+    x = torch.randn(n, L0, device=dev)
+    ops.prepare_bag(x)
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); ops.prepare_bag(x); b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in evs)
+    return round(t[len(t) // 2] * 1e3, 1)
 
 
 def gemm_roofline(timing, n_patches_per_set):
@@ -222,7 +244,7 @@ def time_dropin(n: int, steps: int, warmup: int, dev, host_reads: bool):
     model.train()
     opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4, weight_decay=1e-5)   # get_optim, utils/utils.py:63-65
     loss_fn = torch.nn.CrossEntropyLoss()
-    slides = [make_slide(i, n, dev) for i in range(2)]
+    slides = [make_slide(i, n, dev, prepared=False) for i in range(2)]      # the reference's loop hands fp32 tensors to model(data, sex)
 
     def one(i):
         data, sex, label, site = slides[i % 2]
@@ -314,6 +336,9 @@ def main():
     ap.add_argument("--bag-dtype", choices=["fp32", "fp16"], default="fp32",
                     help="fp16: feature bags stored in half precision (toad_mil_step_x16_f32: two MFMA terms in the first layer, no abs-max pass); "
                          "reported under its own metric name, BASELINE's configurations are fp32")
+    ap.add_argument("--bag-format", choices=["prepared", "fp32"], default="prepared",
+                    help="prepared (default): bags resident in the ingest format of toad_bag_prepare_f32 (two fp16 pieces per fp32 element, "
+                         "plane-tiled; made once per slide); fp32: the raw [N,1024] fp32 tensor, re-measured and re-split by every step")
     ap.add_argument("--patches", type=int, default=0, help="patches per slide (default: 100,000; config 3: 10,000; config 4: 50,000)")
     ap.add_argument("--slides-per-rank", type=int, default=1)
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE.json config (0 = the headline step; 5 = bench_extract.py)")
@@ -325,8 +350,9 @@ def main():
     ap.add_argument("--single-device", action="store_true",
                     help="plumbing test only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     args = ap.parse_args()
-    global BAG_DTYPE
+    global BAG_DTYPE, BAG_PREPARED
     BAG_DTYPE = torch.float16 if args.bag_dtype == "fp16" else torch.float32
+    BAG_PREPARED = args.bag_format == "prepared"
 
     from toad_amd import launch
     if args.config == 5:                                   # BASELINE config 5 lives in bench_extract.py (same contract, same flags)
@@ -456,7 +482,9 @@ def main():
             "dtype": "f32 (storage + accumulation; GEMM operands as 2 x f16 pieces, 3 MFMA terms)" + ("" if args.bag_dtype == "fp32" else "; bag stored as f16"),
             "data": "synthetic",
             "config": {"workload": f"TOAD_fc_mtl_concat(big, n_classes=18) fwd + 0.75/0.25 CE + bwd + Adam on "
-                                   f"{len(slides[0])} x {n}-patch x 1024-d N(0,1) bag(s) per GPU per step, bags resident in HBM"
+                                   f"{len(slides[0])} x {n}-patch x 1024-d N(0,1) fp32 bag(s) per GPU per step, bags resident in HBM"
+                                   + (" in the ingest format (toad_bag_prepare_f32, once per slide: both fp16 pieces of every fp32 element, plane-tiled, 4 B/element)"
+                                      if (BAG_PREPARED and args.bag_dtype == "fp32" and n >= 64) else " as raw tensors")
                                    + (f"; 64 slides per optimiser step dealt round robin over {world} rank(s)" if args.config == 4 else ""),
                        "arithmetic": "fp32 storage/accumulation; GEMM operands as two fp16 pieces (x*s = h+m, power-of-two scales), 3 MFMA terms = "
                                      "fp32-equivalent, verified vs fp64 (tools/split_emulation.py, tests/test_gpu_h2.py)",
@@ -479,6 +507,19 @@ def main():
                                 "seconds": round(sus_t, 3), "ms_per_step": round(sus_t / sus_steps * 1e3, 3)}
         out["allreduce"] = allreduce
         out["last_loss"] = round(last_loss, 5)
+        if world == 1 and args.config in (0, 3) and BAG_PREPARED and args.bag_dtype == "fp32" and n >= 64:
+            # the same K steps on RAW fp32 bags (abs-max pass + in-kernel splitting of the bag every step), and the one-off cost of preparing a bag
+            raw = [[make_slide((rank * args.slides_per_rank + s_) * nbags + b, n, dev, prepared=False) for s_ in range(args.slides_per_rank)] for b in range(nbags)]
+            for i in range(3):
+                dp.step(raw[i % nbags], global_slides)
+            sync(); t2 = time.perf_counter()
+            for i in range(args.steps):
+                dp.step(raw[i % nbags], global_slides)
+            sync(); raw_ms = (time.perf_counter() - t2) / args.steps * 1e3
+            del raw
+            out["fp32_bag"] = {"value": round(global_slides * 1e3 / raw_ms, 3), "unit": "slides/s", "ms_per_step": round(raw_ms, 3), "steps": args.steps,
+                               "what": "same step on raw fp32 [N,1024] bags (toad_mil_step_f32: per-step abs-max pass + in-kernel splitting of the bag)",
+                               "prepare_us_per_bag": time_prepare(n, dev)}
         if world == 1 and args.config in (0, 3) and not args.no_dropin:
             k = max(args.steps, 10)
             ms = time_dropin(n, k, 3, dev, host_reads=False)

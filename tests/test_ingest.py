@@ -104,3 +104,32 @@ def test_copies_overlap_with_compute(cuda):
     # at least 30 % of the shorter phase must hide behind the longer one (measured: 32.8 ms against 29.0 + 17.2; the bound
     # is 41 ms, loose enough for a noisy box, and a serialised pipeline at 46 ms still fails it)
     assert t_overlap < t_copy + t_compute - 0.3 * min(t_copy, t_compute), (t_copy, t_compute, t_overlap)
+
+
+@pytest.mark.gpu
+def test_prefetcher_prepares_bags_on_the_copy_stream(cuda):
+    """BagPrefetcher(prepare=True) yields PreparedBag objects (toad_bag_prepare_f32 on the copy stream, behind the H2D copy): a
+    training step on them gives the loss and logits of the fp32 tensors bitwise, in record order, with copies still in flight."""
+    from toad_amd import TOAD_fc_mtl_concat, ops
+    from toad_amd.ingest import BagPrefetcher
+    recs = _records(5, rows=700)
+    torch.manual_seed(3)
+    model = TOAD_fc_mtl_concat(n_classes=18); model.relocate(); model.train()
+    w = {k: v.detach() for k, v in model._weights().items()}
+
+    def losses(loader):
+        out = []
+        for bag, label, site, sex in loader:
+            g = {k: torch.zeros_like(w[k]) for k in ops.STEP_SLOTS}
+            loss, logits, _ = ops.mil_step(w, g, 0.0, bag, sex, label, site, want_logits=True)
+            out.append((loss.cpu(), logits.cpu(), g["w2"].cpu()))
+        return out
+    plain = losses(BagPrefetcher(recs, cuda, depth=2))
+    prep_loader = BagPrefetcher(recs, cuda, depth=3, prepare=True)
+    first = next(iter(prep_loader))[0]
+    assert getattr(first, "is_prepared_bag", False) and first.shape == (700, 1024)
+    prep = losses(prep_loader)
+    for a, b in zip(plain, prep):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    with pytest.raises(ValueError):
+        BagPrefetcher(recs, cuda, dtype=torch.float16, prepare=True)

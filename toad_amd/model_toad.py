@@ -255,13 +255,31 @@ class TOAD_fc_mtl_concat(nn.Module):
                 if h.shape[0] == 0:
                     a_raw = F_.attention_scores(wd, h, drop_p, seed)
                 else:                                             # trunk + scores in one library call, no pooling / heads
-                    a_raw = ops.mil_fwd(wd, h, None, drop_p, seed, attention_only=True).view("a_raw", (h.shape[0], 2))
-            return a_raw.t()[0]                                   # model_toad.py:92-94: raw task-0 scores, [N]
+                    # cached arena + a copy of the scores: a view would pin the whole arena (7 KB per patch) behind an [N] result
+                    a_raw = ops.mil_fwd(wd, h, None, drop_p, seed, attention_only=True, cached_arena=True).view("a_raw", (h.shape[0], 2))
+                    return a_raw[:, 0].clone()                    # model_toad.py:92-94: raw task-0 scores, [N]
+            return a_raw.t()[0]
         _require_cuda(sex, "sex")
         sex = sex.to(torch.float32).reshape(1).contiguous()
         sp = [w[k] for k in F_.SLOTS]
-        logits, site_logits, a_nt, feats, y_prob, y_hat, site_prob, site_hat = F_.ToadMIL.apply(
-            h, sex, *sp, w["wab"], w["bab"], drop_p, seed)
+        need_grad = torch.is_grad_enabled() and (h.requires_grad or sex.requires_grad or any(p.requires_grad for p in sp))
+        if not need_grad and h.shape[0] > 0:
+            # no backward will follow (eval / no_grad / frozen model): the saved activations (H1, H, P: ~7 KB per patch) go to a cached
+            # arena that the next such forward reuses, and the small outputs are COPIED out - a view would keep 0.7 GB alive per
+            # 100k-patch slide for as long as a caller holds Y_prob (validate / summary append them for a whole epoch)
+            wd = {k: v.detach() for k, v in w.items()}
+            arena = ops.mil_fwd(wd, h, sex, drop_p, seed, cached_arena=True)
+            n, c = h.shape[0], wd["wcls"].shape[0]
+            v = arena.view
+            small = torch.cat([v("logits", (c,)), v("y_prob", (c,)), v("site_logits", (2,)), v("site_prob", (2,)), v("mcat", (2 * 513,))])  # one small copy
+            logits, y_prob, site_logits, site_prob, feats = small[:c].view(1, c), small[c:2 * c].view(1, c), small[2 * c:2 * c + 2].view(1, 2), \
+                small[2 * c + 2:2 * c + 4].view(1, 2), small[2 * c + 4:].view(2, 513)
+            hats = torch.cat([v("y_hat", (1,), torch.int64), v("site_hat", (1,), torch.int64)])
+            y_hat, site_hat = hats[0:1].view(1, 1), hats[1:2].view(1, 1)
+            a_nt = v("a_raw", (n, 2)).clone()
+        else:
+            logits, site_logits, a_nt, feats, y_prob, y_hat, site_prob, site_hat = F_.ToadMIL.apply(
+                h, sex, *sp, w["wab"], w["bab"], drop_p, seed)
         results_dict = {}
         if return_features:
             results_dict.update({"features": feats})              # M after the sex concat, [2, L+1]

@@ -410,6 +410,9 @@ class PreparedBag:
     def contiguous(self):
         return self
 
+    def to(self, *args, **kwargs):           # already resident in its final form (train._to_device calls data.to(device))
+        return self
+
     def nbytes(self) -> int:
         return self.planes.numel() + 4 * self.amax.numel()
 
@@ -507,11 +510,15 @@ ARENA_SLOTS = ("h1", "h", "p", "a_raw", "stats", "m", "mcat", "logits", "y_prob"
 class MilArena:
     """The forward arena of one slide: saved activations + outputs, as typed views of ONE allocation."""
 
-    def __init__(self, n: int, c: int, d: int, device):
+    def __init__(self, n: int, c: int, d: int, device, cached: bool = False):
+        """``cached``: carve the arena out of the per-(device, stream) workspace cache instead of a fresh allocation - for forwards
+        whose activations nobody will read back (no_grad / eval): the caller must CLONE the outputs it keeps, since the next
+        cached forward overwrites them (a view of a fresh arena would pin ~7 KB per patch for as long as any output lives)."""
         import ctypes
         lib = _lib.load()
         self.n, self.c, self.d = n, c, d
-        self.buf = torch.empty(int(lib.toad_mil_arena_bytes(n, c, d)), dtype=torch.uint8, device=device)
+        nbytes = int(lib.toad_mil_arena_bytes(n, c, d))
+        self.buf = _ws(nbytes, device, "eval_arena")[:nbytes] if cached else torch.empty(nbytes, dtype=torch.uint8, device=device)
         align = int(lib.toad_mil_buffer_align(n))
         self.base = (-self.buf.data_ptr()) % align
         offs = (ctypes.c_int64 * len(ARENA_SLOTS))()
@@ -527,8 +534,9 @@ class MilArena:
 
 
 def mil_fwd(w, bag, sex, drop_p: float = 0.0, seed: int = 0, attention_only: bool = False,
-            x_amax: Optional[torch.Tensor] = None) -> MilArena:
-    """models/model_toad.py:90-116 for one bag in ONE library call; returns the arena (outputs + what backward needs)."""
+            x_amax: Optional[torch.Tensor] = None, cached_arena: bool = False) -> MilArena:
+    """models/model_toad.py:90-116 for one bag in ONE library call; returns the arena (outputs + what backward needs).
+    ``cached_arena``: forward-only use (see MilArena): clone what you keep."""
     half = _chk_bag(bag)
     _chk(sex, "sex", allow_none=attention_only); _chk(x_amax, "x_amax", allow_none=True)
     ws_t = [w[k] for k in STEP_SLOTS]
@@ -536,7 +544,7 @@ def mil_fwd(w, bag, sex, drop_p: float = 0.0, seed: int = 0, attention_only: boo
         _chk(t, k)
     n, c, d = _step_dims(w, bag)
     lib = _lib.load()
-    arena = MilArena(n, c, d, bag.device)
+    arena = MilArena(n, c, d, bag.device, cached=cached_arena)
     scratch = _ws(lib.toad_mil_scratch_bytes(n, c, d), bag.device, "mil")
     with _timed("mil_fwd"):
         if half == 2:

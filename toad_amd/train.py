@@ -87,6 +87,20 @@ def _fused_ok(model, optimizer, loss_fn) -> bool:
             return False
     if any(not p.requires_grad for p in model.parameters()):
         return False
+    # the fused step writes gradients straight into views every parameter's .grad aliases (beta = 0: whatever .grad held is
+    # overwritten, autograd hooks never fire). That is only the reference's semantics when nothing hangs on the autograd path and
+    # the optimiser steps exactly this model's parameters:
+    if any(getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None) for p in model.parameters()):
+        return False                                             # gradient hooks (clipping, logging): take the autograd path
+    from .optim import FlatAdam, FlatSGD
+    if optimizer is not None and not isinstance(optimizer, (FlatAdam, FlatSGD)):
+        groups = getattr(optimizer, "param_groups", None)
+        if groups is None:
+            return False
+        owned = {id(p) for g in groups for p in g["params"]}
+        mine = {id(p) for p in model.parameters()}
+        if owned != mine:                                        # a subset / other tensors: the fused path would silently train something else
+            return False
     return True
 
 
@@ -115,6 +129,7 @@ def train_loop(epoch: int, model, loader: Iterable, optimizer, n_classes: int, l
         from .model_toad import _draw_dropout
         from .optim import FlatAdam, FlatSGD
         fg = _fused_grads(model)
+        fg.bind()                                                     # .grad views for every optimiser kind: inspection / clipping see the gradients
         flat_opt = isinstance(optimizer, (FlatAdam, FlatSGD))
         if flat_opt and optimizer.p is not fg.flat:
             raise RuntimeError("train_loop: the flat optimiser was built for a parameter buffer the model no longer uses")
@@ -192,8 +207,9 @@ def _auc(labels: np.ndarray, probs: np.ndarray, n_classes: int) -> float:
 
 
 @torch.no_grad()
-def validate(model, loader: Iterable, n_classes: int, loss_fn=None, with_auc: bool = True, group_rows: int = 131072) -> Dict[str, object]:
-    """Forward-only pass (reference ``validate`` / ``summary``): losses, errors, per-slide probabilities, AUCs."""
+def validate(model, loader: Iterable, n_classes: int, loss_fn=None, with_auc: bool = True, group_rows: int = 0) -> Dict[str, object]:
+    """Forward-only pass (reference ``validate`` / ``summary``): losses, errors, per-slide probabilities, AUCs. ``group_rows`` > 0 opts into
+    ``eval.forward_grouped``'s ragged multi-slide forward (default 0: one ``model(data, sex)`` per slide, like the reference)."""
     device = next(model.parameters()).device
     loss_fn = loss_fn or nn.CrossEntropyLoss()
     model.eval()
