@@ -294,6 +294,19 @@ def time_allreduce(dp, dev, world: int, backend: str):
     return info
 
 
+def emit(out: dict) -> None:
+    """Print THE json line as the last thing on stdout. Libraries that write through C stdio (RCCL prints a version banner when a
+    communicator is created) sit in a buffer that is only flushed at exit when stdout is a pipe - i.e. after Python's own line;
+    flush it first."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                        # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def run_config2(args, dev):
     """Pool forward only, one resident 100k-patch bag (BASELINE config 2)."""
     from toad_amd import ops
@@ -325,7 +338,7 @@ def run_config2(args, dev):
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_pool(n)
         out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 def main():
@@ -340,7 +353,9 @@ def main():
                     help="prepared (default): bags resident in the ingest format of toad_bag_prepare_f32 (two fp16 pieces per fp32 element, "
                          "plane-tiled; made once per slide); fp32: the raw [N,1024] fp32 tensor, re-measured and re-split by every step")
     ap.add_argument("--patches", type=int, default=0, help="patches per slide (default: 100,000; config 3: 10,000; config 4: 50,000)")
-    ap.add_argument("--slides-per-rank", type=int, default=1)
+    ap.add_argument("--slides-per-rank", type=int, default=0,
+                    help="slides per rank per optimiser step (default 1; config 3: 8). Several small fp32 slides of a rank go through ONE "
+                         "ragged multi-slide call (toad_mil_multi_step_f32: the GEMMs run once over the concatenated bags)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE.json config (0 = the headline step; 5 = bench_extract.py)")
     ap.add_argument("--sustain-seconds", type=float, default=8.0, help="length of the sustained leg after the timed region (0 = skip)")
     ap.add_argument("--dropin", action="store_true", help="time only the reference's call sequence on the drop-in module")
@@ -407,7 +422,9 @@ def main():
         scaling = "strong"
     else:
         n = args.patches or (10_000 if args.config == 3 else 100_000)
-        spr = args.slides_per_rank
+        spr = args.slides_per_rank or (8 if args.config == 3 else 1)
+        if spr > 1 and n <= SlideShardedDP.BATCH_MAX_PATCHES:
+            BAG_PREPARED = False                                       # the ragged batch call concatenates raw fp32 bags
         nbags = 2                                                      # alternate two resident bags per slide slot
         slides = [[make_slide((rank * spr + s) * nbags + b, n, dev) for s in range(spr)] for b in range(nbags)]
         global_slides = spr * world
@@ -489,6 +506,9 @@ def main():
                        "arithmetic": "fp32 storage/accumulation; GEMM operands as two fp16 pieces (x*s = h+m, power-of-two scales), 3 MFMA terms = "
                                      "fp32-equivalent, verified vs fp64 (tools/split_emulation.py, tests/test_gpu_h2.py)",
                        "patches_per_slide": n, "slides_per_step": global_slides,
+                       "batching": ("one ragged multi-slide call per rank and step (toad_mil_multi_step_f32: trunk / attention GEMMs once over the "
+                                    "concatenated bags, pooling + heads + loss per slide; the concatenation is inside the timed step)"
+                                    if (len(slides[0]) > 1 and n <= SlideShardedDP.BATCH_MAX_PATCHES and args.bag_dtype == "fp32") else "one library call per slide"),
                        "parallelism": f"slide-sharded dp{world}, one {4 * model.flat_parameters().numel() / 1e6:.2f} MB grad all-reduce/step"},
         }
         if "pool_fwd" in timing:
@@ -509,7 +529,7 @@ def main():
         out["last_loss"] = round(last_loss, 5)
         if world == 1 and args.config in (0, 3) and BAG_PREPARED and args.bag_dtype == "fp32" and n >= 64:
             # the same K steps on RAW fp32 bags (abs-max pass + in-kernel splitting of the bag every step), and the one-off cost of preparing a bag
-            raw = [[make_slide((rank * args.slides_per_rank + s_) * nbags + b, n, dev, prepared=False) for s_ in range(args.slides_per_rank)] for b in range(nbags)]
+            raw = [[make_slide((rank * spr + s_) * nbags + b, n, dev, prepared=False) for s_ in range(spr)] for b in range(nbags)]
             for i in range(3):
                 dp.step(raw[i % nbags], global_slides)
             sync(); t2 = time.perf_counter()
@@ -531,10 +551,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.config in (0, 3):
             out["cpu_baseline"] = cpu_baseline_step(n, budget_s=30.0 if n >= 50_000 else 15.0, min_reps=3 if n >= 50_000 else 10)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
-    if dist.is_initialized():
+    if dist.is_initialized():                                 # tear the communicator down first: the JSON line stays the LAST line on stdout
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        emit(out)
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@ if REPO not in sys.path:
 import torch
 import torch.distributed as dist
 
-from bench import C, MFMA_EQ_PEAK, SPLIT_TERMS, _physical_cores
+from bench import C, MFMA_EQ_PEAK, SPLIT_TERMS, _physical_cores, emit
 
 FLOP_PER_TILE = 8_562_671_616          # sum of 2*M*K*N over the 43 convolutions at 256x256 (stem K = 147), SURVEY 8d config 5: 8.56 GFLOP
 
@@ -79,13 +79,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    from toad_amd import launch
+    launch.maybe_self_launch(__file__, sys.argv[1:], args.gpus)          # started plainly with --gpus N: spawn the N ranks
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one process per GPU (or run this script plainly)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        launch.init_process_group("nccl", device=dev)
 
     from toad_amd import TOAD_fc_mtl_concat
     from toad_amd.dp import SlideShardedDP
@@ -151,10 +153,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_extractor_baseline()
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        emit(out)
 
 
 if __name__ == "__main__":

@@ -372,6 +372,21 @@ int toad_mil_step_xp_f32(const float *const *params, float *const *grads, float 
                          float *loss_out, float *logits_out, float *site_logits_out,
                          void *ws, size_t ws_bytes, void **events, void *stream);
 
+/* ---- ragged multi-slide training step (ABI 9) -------------------------------------------------------------------------------
+ * One call = forward + weighted CE + backward for a BATCH of B slides whose bags lie concatenated in Xcat [sum N_b, 1024]
+ * (reference loop body: utils/core_utils_mtl_concat.py:200-234, one slide per iteration; data-parallel semantics: one optimiser
+ * step per batch, toad_amd/dp.py). The five trunk / attention GEMMs of the forward and of the backward run ONCE over all rows;
+ * pooling, heads and loss run per slide on row ranges. grads = beta*grads + sum_b d loss_b (fold 1/B into w_cls / w_site).
+ *   offsets : HOST array [B+1] of row offsets (offsets[0] = 0, strictly increasing); sex / label / site : DEVICE arrays [B];
+ *   loss_out [B][3] (weighted loss, cls CE, site CE); logits_out [B][C], site_logits_out [B][2] (either may be NULL);
+ *   ws >= toad_mil_multi_ws_bytes(sum N_b, B, C, D). Agrees with B calls of toad_mil_step_f32 to fp32 round-off (operand scales
+ *   are taken per 256-row block of the concatenation), not bitwise. */
+size_t toad_mil_multi_ws_bytes(int64_t Ntot, int B, int C, int D);
+int toad_mil_multi_step_f32(const float *const *params, float *const *grads, float beta, const float *Xcat,
+                            const int64_t *offsets, int B, const float *sex, const int64_t *label, const int64_t *site,
+                            float w_cls, float w_site, int C, int D, float drop_p, uint64_t seed,
+                            float *loss_out, float *logits_out, float *site_logits_out, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

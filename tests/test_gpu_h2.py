@@ -329,3 +329,77 @@ def test_fp16_bag_equals_the_upcast_bag(cuda, n):
             arena = ops.mil_fwd(w, x16, sex)
             ops.mil_bwd(w, gr16, 0.0, x16, arena, torch.zeros(1, c).cuda(), torch.zeros(1, 2).cuda(), need_dx=True)
     assert ops.x16_ok(n) == (n >= 64)                 # below 64 patches the bag is up-cast (the small wgrad kernel is fp32-only)
+
+
+# ---- dynamic range INSIDE a scale group (review item: the tests above only vary magnitudes BETWEEN 256-row blocks) -----------------
+# The two-piece operand x*s = h + m carries 22 bits relative to x as long as m is a normal fp16 number, i.e. for |x| >= 2^-17 of the
+# abs-max its scale s was derived from; below that m goes subnormal and the representation error becomes ABSOLUTE: <= 2^-39 of that
+# abs-max (gemm_h2.inc header). Sums over such operands therefore obey
+#     |err| <= c * eps32 * sum_k |a_k b_k|   +   2^-38 * ( amax_A * sum_k |b_k|  +  amax_B * sum_k |a_k| )
+# (c covers the representation of both operands, the dropped m.m term and the fp32 ACCUMULATION of K terms, whose round-off walks like
+# sqrt(K) * eps32 * |partial sum| in any fp32 GEMM - the reference's CPU sgemm included: c = max(6, 0.75 sqrt(K)))
+# with amax_A / amax_B the abs-max of the scale group (NT: the A row's 256-row block and the weight ROW; TN: the whole tensor, or the
+# row tile for a prepared operand). These tests assert exactly that bound against fp64, on data built to sit in the absolute regime.
+_EPS = 2.0 ** -24
+
+
+def _nt_bound(x, w, blk_amax_rows, w_row_amax, c=None):
+    c = max(6.0, 0.75 * x.shape[1] ** 0.5) if c is None else c
+    ax, aw = x.double().abs(), w.double().abs()
+    return c * _EPS * (ax @ aw.t()) + 2.0 ** -38 * (blk_amax_rows.double().view(-1, 1) * aw.sum(1).view(1, -1) + ax.sum(1).view(-1, 1) * w_row_amax.double().view(1, -1))
+
+
+@pytest.mark.parametrize("kind", ["decades_in_block", "heavy_tail", "one_giant_row"])
+def test_nt_rows_far_below_their_blocks_abs_max(cuda, kind):
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(21)
+    m, k, n = 1024, 1024, 512
+    x = torch.randn(m, k, generator=g)
+    if kind == "decades_in_block":          # rows at 2^0, 2^-10, 2^-20, 2^-30 of the block maximum, interleaved inside every 256-row block
+        x *= torch.pow(2.0, -10.0 * (torch.arange(m) % 4).float()).view(-1, 1)
+    elif kind == "heavy_tail":              # log-normal magnitudes (sigma = 4: ~8 decades) per ELEMENT, as ReLU features with rare huge activations
+        x = x.sign() * torch.exp(4.0 * torch.randn(m, k, generator=g)).clamp(max=1e12)
+    else:                                   # one row 2^24 above everything else in its block
+        x[300] *= 2.0 ** 24
+    w = torch.randn(n, k, generator=g) * 0.05
+    w[::7] *= 1e-5                          # weight rows carry their own scale: small rows must stay relatively accurate
+    y = ops.linear_act_fwd(x.to(cuda), w.to(cuda), None, 0).cpu().double()
+    ref = x.double() @ w.double().t()
+    blk = torch.stack([x[i:i + 256].abs().max() for i in range(0, m, 256)]).repeat_interleave(256)
+    bound = _nt_bound(x, w, blk, w.abs().max(1).values)
+    assert torch.isfinite(y).all()
+    viol = ((y - ref).abs() - bound).max().item()
+    assert viol <= 0.0, (kind, viol)
+    # the small rows are NOT flushed: wherever a row sits above 2^-17 of its block maximum its result is relatively accurate
+    big_enough = x.abs().max(1).values >= blk * 2.0 ** -17
+    rel = ((y - ref).abs().sum(1) / ref.abs().sum(1).clamp_min(1e-300))[big_enough]
+    assert rel.max().item() <= 2e-5, (kind, rel.max().item())
+
+
+@pytest.mark.parametrize("prepared", [False, True])
+def test_tn_attention_weighted_rows_spanning_ten_decades(cuda, prepared):
+    """Weight gradient dW = dY^T X with dY rows scaled by softmax weights from 1 down to 1e-10 (what a peaked attention does to dZ)
+    and heavy-tailed features: the reduction runs over ALL rows with one scale per operand (per row tile for a prepared X), so small
+    rows live in the absolute regime; the sum must still be within the bound above of the fp64 value."""
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(22)
+    m, i, j = 3000, 512, 1024
+    p = torch.pow(10.0, -10.0 * torch.rand(m, generator=g))
+    p[17] = 1.0
+    dy = torch.randn(m, i, generator=g) * p.view(-1, 1)
+    x = torch.randn(m, j, generator=g) * torch.exp(1.5 * torch.randn(m, 1, generator=g))     # per-row magnitudes over ~3 decades
+    xd = x.to(cuda)
+    dw, db = ops.linear_wgrad(dy.to(cuda), ops.prepare_bag(xd) if prepared else xd)
+    ref = dy.double().t() @ x.double()
+    ady, ax = dy.double().abs(), x.double().abs()
+    # scale groups: dY one abs-max for the tensor; X one for the tensor, or one per 256-row tile when prepared (then sum tile-wise)
+    if prepared:
+        xa = torch.stack([x[r:r + 256].abs().max() for r in range(0, m, 256)]).repeat_interleave(256)[:m].double()
+        floor = 2.0 ** -38 * (dy.abs().max().double() * ax.sum(0).view(1, -1) + (ady * xa.view(-1, 1)).sum(0).view(-1, 1))
+    else:
+        floor = 2.0 ** -38 * (dy.abs().max().double() * ax.sum(0).view(1, -1) + x.abs().max().double() * ady.sum(0).view(-1, 1))
+    bound = max(6.0, 0.75 * m ** 0.5) * _EPS * (ady.t() @ ax) + floor
+    viol = ((dw.cpu().double() - ref).abs() - bound).max().item()
+    assert viol <= 0.0, viol
+    assert ((dw.cpu().double() - ref).abs().max() / ref.abs().max()).item() <= 1e-6        # and it is fp32-accurate at the tensor's scale
+    assert (db.cpu().double() - dy.double().sum(0)).abs().max().item() <= 8 * _EPS * ady.sum(0).max().item()

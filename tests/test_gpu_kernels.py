@@ -103,7 +103,10 @@ def test_gated_pool_fwd(cuda, n, d, l, t):
     assert torch.equal(only, a_raw)
 
 
-@pytest.mark.parametrize("d,l,t", [(256, 512, 2), (256, 1024, 1), (384, 1024, 2), (384, 512, 1)])
+@pytest.mark.parametrize("d,l,t", [(256, 512, 2), (256, 1024, 1), (384, 1024, 2), (384, 512, 1),
+                                   # shapes only the covering instantiation serves (any L, D, n_tasks Attn_Net_Gated's constructor takes
+                                   # up to L 1024, D 512, 4 tasks: models/model_toad.py:19): multiples of 128, odd sizes, more tasks
+                                   (128, 768, 3), (512, 640, 4), (100, 200, 1), (512, 1024, 4), (384, 512, 3), (4, 8, 1), (256, 1024, 2), (260, 520, 2)])
 def test_gated_pool_other_shapes(cuda, d, l, t):
     from toad_amd import ops
     n = 777

@@ -4,11 +4,14 @@ import pytest
 import torch
 
 from oracle import toad_oracle as orc
-from tests.helpers import SLOT2KEY, assert_grad_close, case_inputs, check_outputs_vs_golden, grad_scale, relu_flips
+from tests.helpers import (LAYER2_KEYS, MASK_FREE_KEYS, SLOT2KEY, assert_grad_close, case_inputs, check_outputs_vs_golden, grad_scale,
+                           relu_flips)
 
 pytestmark = pytest.mark.gpu
 
 CASES = ["n0", "n1", "n2", "n63", "n64", "n65", "n256", "n777", "n777_c2", "n1024_sat", "n300_equal", "n10000", "n100000"]
+FLIPS = {}              # case -> (legitimate ReLU-mask flips in layer 1, in layer 2), filled by test_module_matches_reference_golden
+MAX_FLIP_CASES = 4      # of the 13 golden cases, at most this many may have ANY gradient compared with something other than the golden values
 
 
 def _model(c, params, cuda):
@@ -40,24 +43,50 @@ def test_module_matches_reference_golden(cuda, golden, name):
     # and the gradient is compared with the fp64 backward on the device's own activations instead (same bound, identical masks).
     from toad_amd import functional as F_
     w = {s_: ci["params"][k].to(cuda) for s_, k in SLOT2KEY.items()}
-    n_flips = 0
+    f1 = f2 = 0
     if ci["n"] > 0:
         outs, sv = F_.mil_forward(w, data, sex)
         assert torch.equal(outs["logits"], res["logits"].detach())          # the per-op route is bitwise the module's
-        n_flips = relu_flips(ci["params"], ci["x"], sv.h1, sv.h)
-    check_outputs_vs_golden(golden, name, out, loss.item(), grads if n_flips == 0 else None, atol=1e-4)
+        f1, f2 = relu_flips(ci["params"], ci["x"], sv.h1, sv.h)
+    FLIPS[name] = (f1, f2)
+    n_flips = f1 + f2
+    # against the REFERENCE's golden gradients: all 14 when no mask flipped; otherwise every gradient a flip cannot reach (the ten
+    # attention / head gradients always, layer 2's as well when only layer-1 masks flipped) - see tests/helpers.py MASK_FREE_KEYS
+    golden_keys = None if n_flips == 0 else (MASK_FREE_KEYS + (LAYER2_KEYS if f2 == 0 else ()))
+    check_outputs_vs_golden(golden, name, out, loss.item(), grads, atol=1e-4, grad_keys=golden_keys)
     if n_flips:
+        # the gradients downstream of a flipped mask: fp64 backward on the device's own activations (identical masks), same bound
         dl, ds = orc.loss_grad(outs["logits"].cpu(), ci["label"], outs["site_logits"].cpu(), ci["site"])
         sv_cpu = orc.Saved(x=ci["x"], h1=sv.h1.cpu(), h=sv.h.cpu(), p=sv.p.cpu(), a_raw=sv.a_raw.cpu(), m=sv.m.cpu(), mcat=sv.mcat.cpu(), sex=ci["sex"])
         s64 = orc.Saved(**{k: (v.double() if (v is not None and v.is_floating_point()) else v) for k, v in sv_cpu.__dict__.items()})
         og = orc.backward({k: v.double() for k, v in ci["params"].items()}, s64, dl.double(), ds.double())
         o32 = orc.backward(ci["params"], sv_cpu, dl, ds)
         for k in orc.PARAM_KEYS:
+            if k in golden_keys:
+                continue
             noise = (o32[k].double() - og[k]).abs().max().item()
-            assert_grad_close(grads[k], og[k], 2e-5, grad_scale(og, k), what=f"{name}:{k} ({n_flips} legit ReLU flips)", floor=10.0 * noise)
+            assert_grad_close(grads[k], og[k], 2e-5, grad_scale(og, k), what=f"{name}:{k} ({f1}+{f2} legit ReLU flips)", floor=10.0 * noise)
     a_only = model(data, sex, attention_only=True)
     assert a_only.shape == (ci["n"],)
     assert torch.equal(a_only, res["A"][0].detach())
+
+
+def test_golden_gradient_comparison_rarely_leaves_the_golden_values():
+    """How many of the golden cases above had a legitimate ReLU-mask flip, i.e. compared SOME gradients (never the ten mask-free
+    ones) with the fp64 backward on the device's activations instead of the reference's captured values. Visible and bounded."""
+    if len(FLIPS) < len(CASES):
+        pytest.skip("runs after test_module_matches_reference_golden in the same process")
+    flipped = {k: v for k, v in FLIPS.items() if sum(v)}
+    print(f"golden cases with legitimate ReLU flips (layer 1, layer 2): {flipped} of {len(FLIPS)}")
+    import json, os
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/golden_flip_cases.json", "w") as f:
+            json.dump({"cases": len(FLIPS), "flipped": flipped, "max_allowed": MAX_FLIP_CASES}, f)
+    except OSError:
+        pass
+    assert len(flipped) <= MAX_FLIP_CASES, flipped
+    assert all(sum(v) <= 64 for v in flipped.values()), flipped     # a handful of boundary elements, not a systematic difference
 
 
 @pytest.mark.parametrize("name", ["n777", "n1024_sat", "n10000", "n100000"])
@@ -236,15 +265,18 @@ def test_non_default_stream_and_autograd_thread(cuda):
         assert all(torch.equal(a, b) for a, b in zip(gs, ref_grads))
 
 
-def test_attn_net_gated_standalone(cuda):
-    """Attn_Net_Gated with its constructor defaults (L=1024, D=256, n_tasks=1; model_toad.py:19)."""
+@pytest.mark.parametrize("shape", [None, (512, 384, 2), (200, 100, 3), (768, 128, 4), (640, 512, 1), (1024, 256, 2)])
+def test_attn_net_gated_standalone(cuda, shape):
+    """Attn_Net_Gated with its constructor defaults (L=1024, D=256, n_tasks=1; model_toad.py:19) and with other (L, D, n_tasks) the
+    constructor accepts: forward scores and all gradients (parameters and input) against autograd on the oracle's formula."""
     from toad_amd import Attn_Net_Gated
     torch.manual_seed(4)
-    net = Attn_Net_Gated().to(cuda)
-    x = torch.randn(999, 1024)
+    l, d, t = shape or (1024, 256, 1)
+    net = (Attn_Net_Gated() if shape is None else Attn_Net_Gated(L=l, D=d, n_tasks=t)).to(cuda)
+    x = torch.randn(999, l)
     xg = x.to(cuda).requires_grad_(True)
     a, xo = net(xg)
-    assert xo is xg and a.shape == (999, 1)
+    assert xo is xg and a.shape == (999, t)
     wa, ba = net.attention_a[0].weight.detach().cpu(), net.attention_a[0].bias.detach().cpu()
     wb, bb = net.attention_b[0].weight.detach().cpu(), net.attention_b[0].bias.detach().cpu()
     wc, bc = net.attention_c.weight.detach().cpu(), net.attention_c.bias.detach().cpu()

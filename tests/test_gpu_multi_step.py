@@ -1,0 +1,130 @@
+"""GPU: the ragged multi-slide training step (toad_mil_multi_step_f32): gradients == the sum of the per-slide gradients - against
+B calls of the one-slide step (same kernels) and against the CPU oracle (the reference's op sequence, oracle/toad_oracle.py)."""
+import pytest
+import torch
+
+from oracle import toad_oracle as orc
+from tests.helpers import SLOT2KEY, assert_grad_close, grad_scale
+
+pytestmark = pytest.mark.gpu
+
+C = 18
+
+
+def _model(cuda, seed=0, dropout=False):
+    from toad_amd import TOAD_fc_mtl_concat
+    torch.manual_seed(seed)
+    m = TOAD_fc_mtl_concat(n_classes=C, dropout=dropout)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.05)
+    params = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.relocate()
+    return m, params
+
+
+def _slides(lens, seed=0):
+    out = []
+    for i, n in enumerate(lens):
+        g = torch.Generator().manual_seed(seed * 1000 + i)
+        out.append((torch.randn(n, 1024, generator=g), torch.tensor([float(i % 2)]), torch.tensor([(7 * i) % C]), torch.tensor([(i // 2) % 2])))
+    return out
+
+
+@pytest.mark.parametrize("lens", [[256] * 8, [1, 2, 63, 300, 1000, 257, 64], [3000, 5000, 777], [10000] * 4, [40]])
+def test_batch_gradient_is_the_sum_of_the_slide_gradients(cuda, lens):
+    from toad_amd import ops
+    model, params = _model(cuda, seed=len(lens))
+    w = {k: v.detach() for k, v in model._weights().items()}
+    slides = _slides(lens, seed=len(lens))
+    dev_slides = [tuple(t.to(cuda) for t in s) for s in slides]
+    B = len(lens)
+    # reference 1: B one-slide steps accumulating (beta = 1) into one buffer, each loss scaled by 1/B
+    g1 = {k: torch.zeros_like(w[k]) for k in ops.STEP_SLOTS}
+    l1, lg1 = [], []
+    for i, (bag, sex, label, site) in enumerate(dev_slides):
+        if bag.shape[0] >= 1:
+            loss, lg, sl = ops.mil_step(w, g1, 0.0 if i == 0 else 1.0, bag, sex, label, site, 0.75 / B, 0.25 / B, want_logits=True)
+        l1.append(loss); lg1.append(lg)
+    # the batch call
+    g2 = {k: torch.full_like(w[k], 3.0) for k in ops.STEP_SLOTS}              # beta = 0 must overwrite
+    sex = torch.cat([s[1] for s in dev_slides]); label = torch.cat([s[2] for s in dev_slides]); site = torch.cat([s[3] for s in dev_slides])
+    loss, logits, slog = ops.mil_multi_step(w, g2, 0.0, [s[0] for s in dev_slides], sex, label, site, 0.75 / B, 0.25 / B, want_logits=True)
+    assert loss.shape == (B, 3) and logits.shape == (B, C)
+    for i in range(B):
+        assert (logits[i] - lg1[i][0]).abs().max().item() <= 2e-5 * max(lg1[i].abs().max().item(), 1.0), i
+        assert (loss[i] - l1[i]).abs().max().item() <= 1e-5, i
+    # The oracle's per-slide gradients, summed - in fp32 (the reference's arithmetic) and in fp64. The two device routes split the GEMMs'
+    # reductions differently (K-slices of remainder tiles depend on the row count), so H1 / H differ by fp32 round-off and a pre-activation
+    # within round-off of zero can land on the other side of the ReLU in one of them: a LEGITIMATE flip moves one dZ element, which moves
+    # a whole row / a rank-one update of the trunk gradients by that patch's contribution. The yardstick for that is, as in the golden
+    # tests, the oracle's OWN fp32-vs-fp64 deviation `dev` (its fp32 run flips too); the ten gradients no ReLU mask reaches have none.
+    p64 = {k: v.double() for k, v in params.items()}
+    tot32 = {k: torch.zeros_like(v) for k, v in params.items()}
+    tot64 = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in params.items()}
+    for (bag, sx, lb, st) in slides:
+        _, _, g = orc.fwd_bwd(params, bag, sx, lb, st)
+        _, _, gd = orc.fwd_bwd(p64, bag.double(), sx.double(), lb, st)
+        for k in tot32:
+            tot32[k] += g[k] / B; tot64[k] += gd[k] / B
+    d = w["wc"].shape[1]
+
+    def full(g):
+        o = dict(g); o["wa"], o["wb"], o["ba"], o["bb"] = g["wab"][:d], g["wab"][d:], g["bab"][:d], g["bab"][d:]
+        return o
+    got1, got2 = full(g1), full(g2)
+    for slot, key in SLOT2KEY.items():
+        dev = (tot32[key].double() - tot64[key]).abs().max().item()
+        sc = grad_scale(tot64, key)
+        assert_grad_close(got2[slot], tot64[key], 2e-5, sc, what=f"batch vs oracle: {key}", floor=10.0 * dev)
+        # and the batch call against B one-slide calls of the same kernels
+        assert_grad_close(got2[slot], got1[slot], 5e-5, sc, what=f"batch vs per-slide: {key}", floor=20.0 * dev)
+    # beta = 1 accumulates on top
+    g3 = {k: g2[k].clone() for k in ops.STEP_SLOTS}
+    ops.mil_multi_step(w, g3, 1.0, [s[0] for s in dev_slides], sex, label, site, 0.75 / B, 0.25 / B)
+    for k in ops.STEP_SLOTS:
+        assert (g3[k] - 2 * g2[k]).abs().max().item() <= 1e-6 * max(g2[k].abs().max().item(), 1e-30) + 1e-12, k
+    # deterministic run to run, and the pre-concatenated form is the same call
+    g4 = {k: torch.zeros_like(w[k]) for k in ops.STEP_SLOTS}
+    xcat = torch.cat([s[0] for s in dev_slides], 0)
+    offs = [0]
+    for n in lens:
+        offs.append(offs[-1] + n)
+    ops.mil_multi_step(w, g4, 0.0, xcat, sex, label, site, 0.75 / B, 0.25 / B, offsets=offs)
+    assert all(torch.equal(g2[k], g4[k]) for k in ops.STEP_SLOTS)
+
+
+def test_dp_step_batches_small_slides(cuda):
+    """SlideShardedDP.step routes a shard of small slides through the multi-slide call by default: same parameters after the step
+    (to round-off) as with the per-slide path, and far fewer library calls."""
+    from toad_amd.dp import SlideShardedDP
+    lens = [300, 512, 64, 1000, 2049, 128]
+    slides = [tuple(t.to(cuda) for t in s) for s in _slides(lens, seed=9)]
+    outs = []
+    for batched in (False, True):
+        model, _ = _model(cuda, seed=4)
+        model.train()
+        dp = SlideShardedDP(model, {"lr": 1e-3, "weight_decay": 1e-5})
+        dp.accumulate(slides, len(slides), batched=batched)
+        outs.append(dp.flat_grad.clone())
+        if batched:
+            losses = dp.step(slides, len(slides))           # default = batched for such a shard
+            assert len(losses) == len(slides) and torch.isfinite(torch.stack([l[0] for l in losses])).all()
+    sc = outs[0].abs().max().item()
+    assert (outs[0] - outs[1]).abs().max().item() <= 5e-5 * sc
+
+
+def test_train_mode_dropout_runs_and_is_seeded(cuda):
+    from toad_amd import ops
+    model, _ = _model(cuda, seed=2, dropout=True)
+    w = {k: v.detach() for k, v in model._weights().items()}
+    slides = [tuple(t.to(cuda) for t in s) for s in _slides([500, 700, 300], seed=3)]
+    sex = torch.cat([s[1] for s in slides]); label = torch.cat([s[2] for s in slides]); site = torch.cat([s[3] for s in slides])
+    res = []
+    for seed in (11, 11, 12):
+        g = {k: torch.zeros_like(w[k]) for k in ops.STEP_SLOTS}
+        loss, _, _ = ops.mil_multi_step(w, g, 0.0, [s[0] for s in slides], sex, label, site, drop_p=0.25, seed=seed)
+        res.append((loss.clone(), g["w1"].clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert not torch.equal(res[0][1], res[2][1]) and torch.isfinite(res[2][1]).all()

@@ -67,6 +67,8 @@ SIGNATURES = {
     "toad_linear_wgrad_xp_f32": (I, [P, P, P, P, P, I64, I64, I64, F, P, P, SZ, P]),
     "toad_mil_fwd_xp_f32": (I, [P, P, P, P, I64, I, I, F, U64, I, P, SZ, P, SZ, P]),
     "toad_mil_bwd_xp_f32": (I, [P, P, F, P, P, I64, I, I, F, U64, P, SZ, P, P, P, P, P, P, SZ, P]),
+    "toad_mil_multi_ws_bytes": (SZ, [I64, I, I, I]),
+    "toad_mil_multi_step_f32": (I, [P, P, F, P, P, I, P, P, P, F, F, I, I, F, U64, P, P, P, P, SZ, P]),
     "toad_mil_step_xp_f32": (I, [P, P, F, P, P, P, P, P, F, F, I64, I, I, F, U64, P, P, P, P, SZ, P, P]),
 }
 

@@ -6,17 +6,19 @@
 // ~7.4 kFLOP per patch -> 1.4 FLOP/B.  No operand is re-read, nothing is staged twice.
 //
 // Work decomposition (gfx950, wave64):
-//  * 16 lanes own one patch row, so a wave streams 4 rows per step; every 16-lane group reads
-//    contiguous 256-B pieces of its row with 16-B/lane loads (full 128-B lines).
-//    A wave step keeps 6+6 (Pa,Pb) + 8 (H) dwordx4 loads in flight per lane = 20 KB / wave.
-//  * the D-long dot products with Wc are reduced with four DPP steps inside the 16-lane row
-//    (quad_perm, quad_perm, row_half_mirror, row_mirror): no LDS, no ds_bpermute.
-//  * online softmax: each 16-lane group carries (m_t, l_t, acc_t[L/16 columns]) in registers;
+//  * 32 lanes own one patch row (LPR), so a wave streams 2 rows per step; every 32-lane group reads
+//    contiguous 512-B pieces of its row with 16-B/lane NON-TEMPORAL loads straight into registers (the rows are
+//    read exactly once, so there is nothing to stage through LDS: a register stream reaches 0.92-0.94 of what a
+//    pure read stream gets on this part). A wave step keeps 3+3 (Pa,Pb) + 4 (H) dwordx4 loads in flight per lane.
+//  * the D-long dot products with Wc are reduced with four DPP steps inside each 16-lane DPP row
+//    (quad_perm, quad_perm, row_half_mirror, row_mirror) and one cross-row exchange: no LDS, no ds_bpermute.
+//  * online softmax: each 32-lane group carries (m_t, l_t, acc_t[L/32 columns]) in registers;
 //    the accumulator is rescaled only when a step raises the running max (wave-uniform branch).
 //  * groups -> waves -> block are merged once at the end through LDS, each block writes one
 //    (m, l, acc) partial; a small second kernel merges the partials, normalises and also
 //    emits (max, sum) per task for the backward pass.
-// Tiles of 16 rows are dealt block-cyclically so all blocks sweep HBM together.
+// Row steps are dealt block-cyclically so all blocks sweep HBM together; two 4-wave workgroups per CU (grid 512) keep the
+// memory pipe busy while one of them computes.
 #include "common.h"
 
 #include <math.h>
@@ -85,24 +87,33 @@ __host__ __device__ inline int64_t pool_partial_floats(int L, int T) { return ((
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int T, int DQ /* = D/(4*LPR) float4 per lane */, int LQ /* = L/(4*LPR) float4 per lane */, bool POOL>
+// GEN = false: the shape IS the template (T tasks, D = 128 DQ, L = 128 LQ): no masking anywhere - the tuned instantiations of the
+// shapes TOAD builds (models/model_toad.py:56,66) and of Attn_Net_Gated's defaults (:19).
+// GEN = true: ONE covering instantiation (T = 4, D <= 512, L <= 1024) serves every other shape Attn_Net_Gated's constructor can be
+// given within those limits (any D, L multiple of 4 / 8, any n_tasks <= 4): the run-time shape (Dr, Lr, Tr) sets the strides, and
+// columns / tasks beyond it carry zeros (zero attention weights, no loads, no stores).
+template <int T, int DQ /* = D/(4*LPR) float4 per lane */, int LQ /* = L/(4*LPR) float4 per lane */, bool POOL, bool GEN = false>
 __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
     const float *__restrict__ Pa, const float *__restrict__ Pb, int64_t ldp, const float *__restrict__ H,
     const float *__restrict__ Wc, const float *__restrict__ bc, float *__restrict__ A_raw,
-    float *__restrict__ partials, int N, DropArgs drop_a, DropArgs drop_b) {
+    float *__restrict__ partials, int N, DropArgs drop_a, DropArgs drop_b, int Dr, int Lr, int Tr) {
     constexpr int D = DQ * 4 * LPR, L = LQ * 4 * LPR;
+    const int D_ = GEN ? Dr : D, L_ = GEN ? Lr : L, T_ = GEN ? Tr : T;      // run-time shape (== the template's unless GEN)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane / LPR, c = lane % LPR;     // LPR-lane group = one row; c = float4 slot
     const bool dropping = drop_a.thresh != 0;       // train-mode Dropout(0.25) after tanh and after sigmoid
+    auto dcol_ok = [&](int j) { return !GEN || (c + LPR * j) * 4 < D_; };
+    auto lcol_ok = [&](int j) { return !GEN || (c + LPR * j) * 4 < L_; };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // Wc columns owned by this lane: float4 index c + LPR j
     f32x4 wc[T][DQ];
     float bcv[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        bcv[t] = bc[t];
+        bcv[t] = (t < T_) ? bc[t] : 0.f;
 #pragma unroll
-        for (int j = 0; j < DQ; ++j) wc[t][j] = ld4(Wc + t * D + (c + LPR * j) * 4);
+        for (int j = 0; j < DQ; ++j) wc[t][j] = (t < T_ && dcol_ok(j)) ? ld4(Wc + t * D_ + (c + LPR * j) * 4) : zero4;
     }
 
     float m[T], l[T];
@@ -125,14 +136,14 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
         f32x4 xa[DQ], xb[DQ];
 #pragma unroll
         for (int j = 0; j < DQ; ++j) {
-            xa[j] = ld4s(pa + 4 * LPR * j);
-            xb[j] = ld4s(pb + 4 * LPR * j);
+            xa[j] = dcol_ok(j) ? ld4s(pa + 4 * LPR * j) : zero4;
+            xb[j] = dcol_ok(j) ? ld4s(pb + 4 * LPR * j) : zero4;
         }
         f32x4 hv[POOL ? LQ : 1];
         if (POOL) {
-            const float *hp = H + rr * L + c * 4;
+            const float *hp = H + rr * L_ + c * 4;
 #pragma unroll
-            for (int j = 0; j < LQ; ++j) hv[j] = ld4s(hp + 4 * LPR * j);
+            for (int j = 0; j < LQ; ++j) hv[j] = lcol_ok(j) ? ld4s(hp + 4 * LPR * j) : zero4;
         }
 
         float s[T];
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
                 if (dropping) {
                     float a, b;
                     gate_ab(xa[j][e], xb[j][e], a, b);
-                    const uint64_t idx = (uint64_t)rr * D + (uint64_t)((c + LPR * j) * 4 + e);
+                    const uint64_t idx = (uint64_t)rr * D_ + (uint64_t)((c + LPR * j) * 4 + e);
                     g = (a * drop_keep(idx, drop_a)) * (b * drop_keep(idx, drop_b));
                 } else {
                     g = gate_g(xa[j][e], xb[j][e]);
@@ -159,11 +170,12 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
         for (int t = 0; t < T; ++t) s[t] = row_allreduce_sum(s[t]) + bcv[t];
 
         if (valid && c == 0) {
-            if (T == 2) {
+            if (T == 2 && !GEN) {
                 *reinterpret_cast<f32x2 *>(A_raw + (int64_t)row * 2) = f32x2{s[0], s[T - 1]};
             } else {
 #pragma unroll
-                for (int t = 0; t < T; ++t) A_raw[(int64_t)row * T + t] = s[t];
+                for (int t = 0; t < T; ++t)
+                    if (t < T_) A_raw[(int64_t)row * T_ + t] = s[t];
             }
         }
 
@@ -199,7 +211,9 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
 
     // ---- merge the 16 (group, wave) partials of this block -------------------------------
     __shared__ float sm_m[NW * RPW][T];
-    __shared__ __attribute__((aligned(16))) float sm_acc[NW][T][L];
+    // exact shapes: one image per wave, summed by all threads; GEN (T*L up to 4096 floats): ONE image the waves add into in turn
+    // (64 KB of static LDS is the limit, and this code runs once per workgroup)
+    __shared__ __attribute__((aligned(16))) float sm_acc[GEN ? 1 : NW][T][L];
     __shared__ float sm_l[NW][T];
     __shared__ float sm_mb[T];
     if (c == 0) {
@@ -207,6 +221,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
         for (int t = 0; t < T; ++t) sm_m[wave * RPW + grp][t] = m[t];
     }
     __syncthreads();
+    f32x4 mg[T][LQ];                       // this lane's columns, rescaled to the block maximum and summed over the wave's row groups
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         float mb = sm_m[0][t];
@@ -219,26 +234,44 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
             f32x4 v = acc[t][j] * f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = groups_sum(v[e]);
-            if (grp == 0) st4(&sm_acc[wave][t][(c + LPR * j) * 4], v);
+            mg[t][j] = v;
+            if (!GEN && grp == 0) st4(&sm_acc[wave][t][(c + LPR * j) * 4], v);
         }
         if (lane == 0) sm_l[wave][t] = lt;
         if (tid == 0) sm_mb[t] = mb;   // block max (same value in every thread)
     }
-    __syncthreads();
-    float *out = partials + (int64_t)blockIdx.x * pool_partial_floats(L, T);
-    for (int e = tid; e < T * L / 4; e += POOL_THREADS) {
-        const int t = e / (L / 4), q = e % (L / 4);
-        f32x4 v = ld4(&sm_acc[0][t][q * 4]);
+    if (GEN) {
+        for (int wv = 0; wv < NW; ++wv) {      // fixed order: deterministic
+            if (wave == wv && grp == 0) {
 #pragma unroll
-        for (int w = 1; w < NW; ++w) v += ld4(&sm_acc[w][t][q * 4]);
-        st4(out + t * L + q * 4, v);
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int j = 0; j < LQ; ++j) {
+                        float *dst = &sm_acc[0][t][(c + LPR * j) * 4];
+                        st4(dst, wv == 0 ? mg[t][j] : ld4(dst) + mg[t][j]);
+                    }
+            }
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
     }
-    if (tid < T) {
+    float *out = partials + (int64_t)blockIdx.x * pool_partial_floats(L_, T_);
+    for (int e = tid; e < T_ * L_ / 4; e += POOL_THREADS) {
+        const int t = e / (L_ / 4), q = e % (L_ / 4);
+        f32x4 v = ld4(&sm_acc[0][t][q * 4]);
+        if (!GEN) {
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += ld4(&sm_acc[w][t][q * 4]);
+        }
+        st4(out + t * L_ + q * 4, v);
+    }
+    if (tid < T_) {
         float lsum = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) lsum += sm_l[w][tid];
-        out[T * L + 2 * tid] = sm_mb[tid];
-        out[T * L + 2 * tid + 1] = lsum;
+        out[T_ * L_ + 2 * tid] = sm_mb[tid];
+        out[T_ * L_ + 2 * tid + 1] = lsum;
     }
 }
 
@@ -301,14 +334,15 @@ __global__ __launch_bounds__(256) void gated_pool_combine_kernel(const float *__
 // Per-block partial: [T][D] dWc then [T] dbc, padded to a multiple of 4 floats (16-byte aligned records)
 __host__ __device__ inline int64_t bwd_partial_floats(int D, int T) { return ((int64_t)T * D + T + 3) & ~(int64_t)3; }
 
-template <int T, int DQ, int LQ>
+template <int T, int DQ, int LQ, bool GEN = false>      // GEN: see gated_pool_fwd_kernel
 __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
     const float *__restrict__ Pa, const float *__restrict__ Pb, int64_t ldp, const float *__restrict__ H,
     const float *__restrict__ Wc, const float *__restrict__ A_raw, const float *__restrict__ stats,
     const float *__restrict__ Mp, const float *__restrict__ dM, const float *__restrict__ dA_ext,
     float *__restrict__ dPa, float *__restrict__ dPb, int64_t ldd, float *__restrict__ dH,
-    float *__restrict__ partials, float *__restrict__ dp_amax, int N, DropArgs drop_a, DropArgs drop_b) {
+    float *__restrict__ partials, float *__restrict__ dp_amax, int N, DropArgs drop_a, DropArgs drop_b, int Dr, int Lr, int Tr) {
     constexpr int D = DQ * 4 * LPR, L = LQ * 4 * LPR;
+    const int D_ = GEN ? Dr : D, L_ = GEN ? Lr : L, T_ = GEN ? Tr : T;
     const bool dropping = drop_a.thresh != 0;
     __shared__ __attribute__((aligned(16))) float s_dm[T][L];
     __shared__ __attribute__((aligned(16))) float s_wc[T][D];
@@ -317,13 +351,21 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
     __shared__ float s_db[NW][T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane / LPR, c = lane % LPR;
+    auto dcol_ok = [&](int j) { return !GEN || (c + LPR * j) * 4 < D_; };
+    auto lcol_ok = [&](int j) { return !GEN || (c + LPR * j) * 4 < L_; };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    for (int e = tid; e < T * L; e += POOL_THREADS) s_dm[e / L][e % L] = dM[e];
-    for (int e = tid; e < T * D; e += POOL_THREADS) s_wc[e / D][e % D] = Wc[e];
+    if (GEN) {          // columns / tasks beyond the run-time shape read as zeros below
+        for (int e = tid; e < T * L; e += POOL_THREADS) s_dm[e / L][e % L] = 0.f;
+        for (int e = tid; e < T * D; e += POOL_THREADS) s_wc[e / D][e % D] = 0.f;
+        __syncthreads();
+    }
+    for (int e = tid; e < T_ * L_; e += POOL_THREADS) s_dm[e / L_][e % L_] = dM[e];
+    for (int e = tid; e < T_ * D_; e += POOL_THREADS) s_wc[e / D_][e % D_] = Wc[e];
     // c_t = dM[t] . M[t]  (one wave per task, fixed order)
-    if (wave < T) {
+    if (wave < T_) {
         float p = 0.f;
-        for (int e = lane; e < L; e += 64) p = fmaf(dM[wave * L + e], Mp[wave * L + e], p);
+        for (int e = lane; e < L_; e += 64) p = fmaf(dM[wave * L_ + e], Mp[wave * L_ + e], p);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
         if (lane == 0) s_c[wave] = p;
@@ -333,9 +375,9 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
     float mt[T], il[T], ct[T], wcm[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        mt[t] = stats[2 * t];
-        il[t] = 1.f / stats[2 * t + 1];
-        ct[t] = s_c[t];
+        mt[t] = (t < T_) ? stats[2 * t] : 0.f;
+        il[t] = (t < T_) ? 1.f / stats[2 * t + 1] : 0.f;
+        ct[t] = (t < T_) ? s_c[t] : 0.f;
         float mw = 0.f;                                     // max |Wc[t,:]| for the abs-max bound of dP below
         for (int e = lane; e < D; e += 64) mw = __builtin_fmaxf(mw, __builtin_fabsf(s_wc[t][e]));
         wcm[t] = h2_wave_max(mw);
@@ -355,31 +397,31 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
         const bool valid = row < N;
         const int64_t rr = valid ? row : 0;
         // issue every load of the step up front
-        const float *hp = H + rr * L + c * 4;
+        const float *hp = H + rr * L_ + c * 4;
         f32x4 hv[LQ];
 #pragma unroll
-        for (int j = 0; j < LQ; ++j) hv[j] = ld4s(hp + 4 * LPR * j);
+        for (int j = 0; j < LQ; ++j) hv[j] = lcol_ok(j) ? ld4s(hp + 4 * LPR * j) : zero4;
         const float *pa = Pa + rr * ldp + c * 4;
         const float *pb = Pb + rr * ldp + c * 4;
         f32x4 xa[DQ], xb[DQ];
 #pragma unroll
         for (int j = 0; j < DQ; ++j) {
-            xa[j] = ld4s(pa + 4 * LPR * j);
-            xb[j] = ld4s(pb + 4 * LPR * j);
+            xa[j] = dcol_ok(j) ? ld4s(pa + 4 * LPR * j) : zero4;
+            xb[j] = dcol_ok(j) ? ld4s(pb + 4 * LPR * j) : zero4;
         }
         float p[T], ds[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const float s = A_raw[rr * T + t];
-            p[t] = valid ? fast_exp(s - mt[t]) * il[t] : 0.f;
-            ds[t] = (dA_ext && valid) ? dA_ext[rr * T + t] : 0.f;
+            const float s = (t < T_) ? A_raw[rr * T_ + t] : 0.f;
+            p[t] = (valid && t < T_) ? fast_exp(s - mt[t]) * il[t] : 0.f;
+            ds[t] = (dA_ext && valid && t < T_) ? dA_ext[rr * T_ + t] : 0.f;
         }
 
         // --- H side: dot_t = dM[t].H[row], dH[row] = sum_t p_t dM[t] (dH == NULL: the dgrad of the attention Linear recomputes it)
         float dot[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) dot[t] = 0.f;
-        float *dhp = dH + rr * L + c * 4;
+        float *dhp = dH + rr * L_ + c * 4;
 #pragma unroll
         for (int j = 0; j < LQ; ++j) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -390,7 +432,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
                 for (int e = 0; e < 4; ++e) dot[t] = fmaf(d[e], hv[j][e], dot[t]);
                 o += p[t] * d;
             }
-            if (valid && dH) st4(dhp + 4 * LPR * j, o);
+            if (valid && dH && lcol_ok(j)) st4(dhp + 4 * LPR * j, o);
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -414,7 +456,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
                 gate_ab(xa[j][e], xb[j][e], a, b);
                 float ka = 1.f, kb = 1.f;           // dropout multipliers (0 or 1/(1-p)), recomputed from the seed
                 if (dropping) {
-                    const uint64_t idx = (uint64_t)rr * D + (uint64_t)((c + LPR * j) * 4 + e);
+                    const uint64_t idx = (uint64_t)rr * D_ + (uint64_t)((c + LPR * j) * 4 + e);
                     ka = drop_keep(idx, drop_a);
                     kb = drop_keep(idx, drop_b);
                 }
@@ -429,7 +471,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
                 oa[e] = dg * bd * ka * (1.f - a * a);
                 ob[e] = dg * ad * kb * b * (1.f - b);
             }
-            if (valid) {
+            if (valid && dcol_ok(j)) {
                 st4(dpa + 4 * LPR * j, oa);
                 st4(dpb + 4 * LPR * j, ob);
             }
@@ -467,19 +509,19 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
         }
     }
     __syncthreads();
-    float *out = partials + (int64_t)blockIdx.x * bwd_partial_floats(D, T);
-    for (int e = tid; e < T * D / 4; e += POOL_THREADS) {
-        const int t = e / (D / 4), q = e % (D / 4);
+    float *out = partials + (int64_t)blockIdx.x * bwd_partial_floats(D_, T_);
+    for (int e = tid; e < T_ * D_ / 4; e += POOL_THREADS) {
+        const int t = e / (D_ / 4), q = e % (D_ / 4);
         f32x4 v = ld4(&s_red[0][t][q * 4]);
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += ld4(&s_red[w][t][q * 4]);
-        st4(out + t * D + q * 4, v);
+        st4(out + t * D_ + q * 4, v);
     }
-    if (tid < T) {
+    if (tid < T_) {
         float bsum = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) bsum += s_db[w][tid];
-        out[T * D + tid] = bsum;
+        out[T_ * D_ + tid] = bsum;
     }
 }
 
@@ -527,17 +569,24 @@ __global__ __launch_bounds__(256) void bwd_partial_reduce_kernel(const float *__
 // (rocprofv3, 100k patches: forward 84 -> 75 us = 6.85 TB/s, backward 172 -> 140 us; three per CU is slower again, profiles/r02ba_*).
 static int pool_grid(int64_t N, bool bwd = false) {
     const int64_t ntiles = (N + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP;
-    static int64_t cap[2] = {0, 0};
-    if (cap[bwd] == 0) {
-        const char *e = getenv(bwd ? "TOAD_POOL_BWD_GRID" : "TOAD_POOL_GRID");      // tuning knobs
-        cap[bwd] = e ? atoll(e) : 512;
-        if (cap[bwd] < 1) cap[bwd] = 512;
-    }
-    return (int)(ntiles < cap[bwd] ? ntiles : cap[bwd]);
+#ifdef TOAD_AB_KNOBS        // tuning knobs of A/B builds only (toad_amd.build.build(defines=("TOAD_AB_KNOBS",), ...))
+    static const int64_t cap_f = [] { const char *e = getenv("TOAD_POOL_GRID"); const int64_t v = e ? atoll(e) : 512; return v < 1 ? 512 : v; }();
+    static const int64_t cap_b = [] { const char *e = getenv("TOAD_POOL_BWD_GRID"); const int64_t v = e ? atoll(e) : 512; return v < 1 ? 512 : v; }();
+    const int64_t cap = bwd ? cap_b : cap_f;
+#else
+    (void)bwd;
+    const int64_t cap = 512;
+#endif
+    return (int)(ntiles < cap ? ntiles : cap);
 }
 
+// Shapes: the tuned instantiations (no masking) for what TOAD builds - TOAD_fc_mtl_concat "big" / "small" (L 512, D 384 / 256, 2 tasks,
+// models/model_toad.py:56,66) and Attn_Net_Gated's constructor defaults (L 1024, D 256, 1 task, :19) - and ONE covering instantiation
+// (GEN: up to 4 tasks, D <= 512, L <= 1024) for every other (L, D, n_tasks) the constructor accepts inside those limits.
+constexpr int GEN_T = 4, GEN_DQ = 4, GEN_LQ = 8;
+static bool exact_shape(int L, int D, int T) { return (T == 1 || T == 2) && (D == 256 || D == 384) && (L == 512 || L == 1024); }
 static bool shape_ok(int L, int D, int T) {
-    return (T == 1 || T == 2) && (D == 256 || D == 384) && (L == 512 || L == 1024);
+    return exact_shape(L, D, T) || (T >= 1 && T <= GEN_T && D >= 4 && D <= GEN_DQ * 4 * LPR && D % 4 == 0 && L >= 8 && L <= GEN_LQ * 4 * LPR && L % 8 == 0);
 }
 
 template <bool POOL>
@@ -547,7 +596,7 @@ static void launch_fwd(int L, int D, int T, int grid, hipStream_t st, const floa
 #define TOAD_FWD_CASE(TT, DD, LL)                                                                             \
     if (T == TT && D == DD && L == LL) {                                                                      \
         hipLaunchKernelGGL((gated_pool_fwd_kernel<TT, DD / (4 * LPR), LL / (4 * LPR), POOL>), dim3(grid), dim3(POOL_THREADS), 0, st, \
-                           Pa, Pb, ldp, H, Wc, bc, A_raw, partials, N, da, db);                               \
+                           Pa, Pb, ldp, H, Wc, bc, A_raw, partials, N, da, db, D, L, T);                      \
         return;                                                                                               \
     }
     TOAD_FWD_CASE(2, 384, 512)
@@ -559,6 +608,8 @@ static void launch_fwd(int L, int D, int T, int grid, hipStream_t st, const floa
     TOAD_FWD_CASE(1, 384, 1024)
     TOAD_FWD_CASE(1, 256, 1024)
 #undef TOAD_FWD_CASE
+    hipLaunchKernelGGL((gated_pool_fwd_kernel<GEN_T, GEN_DQ, GEN_LQ, POOL, true>), dim3(grid), dim3(POOL_THREADS), 0, st, Pa, Pb, ldp, H, Wc, bc,
+                       A_raw, partials, N, da, db, D, L, T);
 }
 
 static void launch_bwd(int L, int D, int T, int grid, hipStream_t st, const float *Pa, const float *Pb, int64_t ldp,
@@ -568,7 +619,7 @@ static void launch_bwd(int L, int D, int T, int grid, hipStream_t st, const floa
 #define TOAD_BWD_CASE(TT, DD, LL)                                                                             \
     if (T == TT && D == DD && L == LL) {                                                                      \
         hipLaunchKernelGGL((gated_pool_bwd_kernel<TT, DD / (4 * LPR), LL / (4 * LPR)>), dim3(grid), dim3(POOL_THREADS), 0, st, Pa, \
-                           Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, partials, dp_amax, N, da, db); \
+                           Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, partials, dp_amax, N, da, db, D, L, T); \
         return;                                                                                               \
     }
     TOAD_BWD_CASE(2, 384, 512)
@@ -580,6 +631,8 @@ static void launch_bwd(int L, int D, int T, int grid, hipStream_t st, const floa
     TOAD_BWD_CASE(1, 384, 1024)
     TOAD_BWD_CASE(1, 256, 1024)
 #undef TOAD_BWD_CASE
+    hipLaunchKernelGGL((gated_pool_bwd_kernel<GEN_T, GEN_DQ, GEN_LQ, true>), dim3(grid), dim3(POOL_THREADS), 0, st, Pa, Pb, ldp, H, Wc, A_raw, stats,
+                       M, dM, dA_ext, dPa, dPb, ldd, dH, partials, dp_amax, N, da, db, D, L, T);
 }
 
 }  // namespace toad
@@ -600,9 +653,9 @@ extern "C" int toad_gated_pool_fwd_f32(const float *Pa, const float *Pb, int64_t
     const DropArgs da = make_drop(drop_p, seed_a), db = make_drop(drop_p, seed_b);
     if (!Pa || !Pb || !Wc || !bc || !A_raw) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (N <= 0 || N > INT32_MAX - 64) { set_error("%s: bad N=%lld", what, (long long)N); return TOAD_EINVAL; }
-    if (!shape_ok(L, D, T)) { set_error("%s: unsupported shape L=%d D=%d T=%d (T in {1,2}, D in {256,384}, L in {512,1024})", what, L, D, T); return TOAD_ESHAPE; }
+    if (!shape_ok(L, D, T)) { set_error("%s: unsupported shape L=%d D=%d T=%d (1 <= T <= 4, D <= 512 multiple of 4, L <= 1024 multiple of 8)", what, L, D, T); return TOAD_ESHAPE; }
     if (ldp < D || ldp % 4 != 0) { set_error("%s: bad ldp=%lld", what, (long long)ldp); return TOAD_ESHAPE; }
-    if (!aligned16(Pa) || !aligned16(Pb) || !aligned16(Wc) || (H && !aligned16(H)) || (T == 2 && ((uintptr_t)A_raw & 7))) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (!aligned16(Pa) || !aligned16(Pb) || !aligned16(Wc) || (H && !aligned16(H)) || (T == 2 && exact_shape(L, D, T) && ((uintptr_t)A_raw & 7))) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
     hipStream_t st = (hipStream_t)stream;
     const int grid = pool_grid(N);
     if (!H) {

@@ -449,3 +449,122 @@ extern "C" int toad_mil_step_xp_f32(const float *const *params, float *const *gr
     return mil_step_impl(params, grads, beta, reinterpret_cast<const float *>(Xp), sex, label, site, w_cls, w_site, N, C, D, drop_p, seed, x_amax,
                          loss_out, logits_out, site_logits_out, ws, ws_bytes, events, stream, TOAD_X_PT, "toad_mil_step_xp_f32");
 }
+
+// ---- ragged multi-slide training step (ABI 9) ---------------------------------------------------------------------------
+// The reference steps once per slide with batch size 1 (utils/utils.py:51-55, utils/core_utils_mtl_concat.py:200-234); its real bags
+// are a few hundred to a few thousand patches, where one slide cannot fill 256 CUs: a 256-patch step is ~23 dependent launches
+// of mostly idle kernels. Under slide-sharded data-parallel semantics (ONE optimiser step per batch of B slides, the gradient is
+// the sum over the batch - toad_amd/dp.py, BASELINE config 4's contract) the rows of different slides never interact before the
+// pooling, so the five trunk / attention GEMMs of the forward AND the backward run ONCE over the concatenated bags
+// Xcat [sum N_b, 1024]; only the softmax pooling, the heads and the loss run per slide, on row ranges of the shared activations.
+//   grads = beta * grads + sum_b d( w_cls * CE(logits_b, label_b) + w_site * CE(site_logits_b, site_b) ) / d params
+// (the caller folds 1/B into w_cls, w_site). Per-slide results: loss_out [B][3], logits_out [B][C], site_logits_out [B][2].
+// offsets: HOST array of B + 1 row offsets (offsets[0] = 0, offsets[B] = sum N_b); sex / label / site: DEVICE arrays of B.
+// Differences from B calls of toad_mil_step_f32, all at fp32 round-off level: GEMM operand scales are taken per 256-row block of
+// the CONCATENATION, and the pooling gradient dH_pool is materialised (per-slide softmax statistics cannot ride in one GEMM
+// epilogue) instead of being recomputed in the dgrad. Train-mode dropout masks hash the element index in the concatenation.
+namespace toad {
+struct MultiSmall { float *stats, *M, *Mcat, *logits, *yprob, *slog, *sprob, *dM; int64_t *yhat, *shat; size_t total; };
+constexpr size_t kSlideRec = 8192;                  // bytes reserved per slide and per small array (>= T*(L+1)*4 = 4104, 256-B multiple)
+static MultiSmall multi_small_layout(int B, char *base) {
+    MultiSmall m{};
+    Carver c;
+    auto P = [&](size_t off) { return base ? base + off : nullptr; };
+    const size_t n = (size_t)B * kSlideRec;
+    m.stats = (float *)P(c.take(n, 256)); m.M = (float *)P(c.take(n, 256)); m.Mcat = (float *)P(c.take(n, 256));
+    m.logits = (float *)P(c.take(n, 256)); m.yprob = (float *)P(c.take(n, 256)); m.slog = (float *)P(c.take(n, 256));
+    m.sprob = (float *)P(c.take(n, 256)); m.dM = (float *)P(c.take(n, 256));
+    m.yhat = (int64_t *)P(c.take(n, 256)); m.shat = (int64_t *)P(c.take(n, 256));
+    m.total = up(c.off, 256);
+    return m;
+}
+}  // namespace toad
+
+extern "C" size_t toad_mil_multi_ws_bytes(int64_t Ntot, int B, int C, int D) {
+    if (B <= 0 || B > 4096 || C > 512) return 0;
+    const size_t a = toad_mil_step_ws_bytes(Ntot, C, D);
+    return a ? a + multi_small_layout(B, nullptr).total + 4096 : 0;
+}
+
+extern "C" int toad_mil_multi_step_f32(const float *const *params, float *const *grads, float beta, const float *Xcat,
+                                        const int64_t *offsets, int B, const float *sex, const int64_t *label, const int64_t *site,
+                                        float w_cls, float w_site, int C, int D, float drop_p, uint64_t seed,
+                                        float *loss_out, float *logits_out, float *site_logits_out, void *ws, size_t ws_bytes, void *stream) {
+    const char *what = "toad_mil_multi_step_f32";
+    if (!params || !grads || !Xcat || !offsets || !sex || !label || !site || !loss_out || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (B <= 0 || B > 4096) { set_error("%s: B must be in [1, 4096]", what); return TOAD_EINVAL; }
+    if (offsets[0] != 0) { set_error("%s: offsets[0] must be 0", what); return TOAD_EINVAL; }
+    for (int b = 0; b < B; ++b) if (offsets[b + 1] <= offsets[b]) { set_error("%s: slide %d is empty or offsets decrease", what, b); return TOAD_EINVAL; }
+    const int64_t N = offsets[B];
+    const MilShape s{N, C, D};
+    if (!shape_ok(s) || !h2_nt_ok(N, kL, kL0, kL0, kL)) { set_error("%s: unsupported shape sum N=%lld C=%d D=%d", what, (long long)N, C, D); return TOAD_ESHAPE; }
+    if (!(drop_p >= 0.f && drop_p < 1.f)) { set_error("%s: drop_p must be in [0,1)", what); return TOAD_EINVAL; }
+    if (!aligned16(Xcat)) { set_error("%s: Xcat must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (ws_bytes < toad_mil_multi_ws_bytes(N, B, C, D)) { set_error("%s: workspace too small", what); return TOAD_EWORKSPACE; }
+    Params p;
+    if (!load_params(params, p, what)) return TOAD_EINVAL;
+    for (int i = 0; i < 12; ++i) if (!grads[i]) { set_error("%s: null gradient slot %d", what, i); return TOAD_EINVAL; }
+    char *ab = align_base(ws, N);
+    int64_t o[TOAD_MIL_ARENA_SLOTS];
+    char *sb = align_base(ab + arena_layout(s, o), N);
+    const Fwd f = arena_view(s, ab);
+    const Scratch w = scratch_layout(s, sb);
+    char *mb = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(sb + w.total) + 255) & ~(uintptr_t)255);
+    const MultiSmall ms = multi_small_layout(B, mb);
+    hipStream_t st = (hipStream_t)stream;
+    const int D2 = 2 * D;
+    const DropSeeds ds = drop_seeds(drop_p, seed);
+    const uint64_t G = 0x9E3779B97F4A7C15ull;
+    const EpiScalars relu1{1, 1.f, make_drop(drop_p, ds.s1)}, relu2{1, 1.f, make_drop(drop_p, ds.s2)}, lin{0, 1.f, make_drop(0.f, 0)};
+    const EpiScalars msk{0, ds.mscale, make_drop(0.f, 0)};
+    const H2Pool nopool{nullptr, nullptr, nullptr, 0};
+    auto rec = [&](void *base, int b) { return reinterpret_cast<char *>(base) + (size_t)b * kSlideRec; };
+
+    // ---- forward: one launch splits the five weight operands and zeroes both groups of abs-max arrays; three GEMMs over all rows
+    {
+        const H2Operand ops5[5] = {{p.w1, kL0, 1, kL, kL0, w.planes[W_1], w.binv[W_1]}, {p.w2, kL, 1, kL, kL, w.planes[W_2], w.binv[W_2]},
+                                   {p.wab, kL, 1, D2, kL, w.planes[W_AB], w.binv[W_AB]}, {p.wab, 1, kL, kL, D2, w.planes[W_ABT], w.binv[W_ABT]},
+                                   {p.w2, 1, kL, kL, kL, w.planes[W_2T], w.binv[W_2T]}};
+        const int nz = (int)(((char *)f.amax_h - (char *)f.amax_x) / sizeof(float) + toad_amax_floats(N));
+        const int nzb = (int)(((char *)w.amax_dZ1 - (char *)w.amax_dP) / sizeof(float) + toad_amax_floats(N));
+        TOAD_TRY(launch_split_h2(ops5, 5, f.amax_x, nz, st, what, w.amax_dP, nzb));
+    }
+    TOAD_TRY(launch_absmax(Xcat, kL0, N, kL0, f.amax_x, false, st, what));
+    TOAD_TRY(launch_nt_h2(Xcat, kL0, f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h1, f.bits_h1, st, what));
+    TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h, nullptr, st, what));
+    TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nullptr, nopool, w.slabs, nullptr, nullptr, st, what));
+    // ---- per slide: fused pool forward on its row range, then heads + weighted CE + heads backward (one single-workgroup launch)
+    for (int b = 0; b < B; ++b) {
+        const int64_t r0 = offsets[b], nb = offsets[b + 1] - r0;
+        float *stats_b = (float *)rec(ms.stats, b), *M_b = (float *)rec(ms.M, b);
+        TOAD_TRY(toad_gated_pool_fwd_f32(f.P + r0 * D2, f.P + r0 * D2 + D, D2, f.H + r0 * kL, p.wc, p.bc, f.A_raw + r0 * kT, M_b, stats_b, w.pool_ws,
+                                         w.pool_ws_bytes, nb, kL, D, kT, drop_p, ds.sa + (uint64_t)b * G, ds.sb + (uint64_t)b * G, st));
+        const float bb = b == 0 ? beta : 1.f;
+        TOAD_TRY(toad_heads_ce_fused_f32(M_b, sex + b, p.wcls, p.bcls, p.wsite, p.bsite, label + b, site + b, w_cls, w_site, (float *)rec(ms.Mcat, b),
+                                         (float *)rec(ms.logits, b), (float *)rec(ms.yprob, b), (int64_t *)rec(ms.yhat, b), (float *)rec(ms.slog, b),
+                                         (float *)rec(ms.sprob, b), (int64_t *)rec(ms.shat, b), loss_out + 3 * b, nullptr, nullptr, grads[8], grads[9],
+                                         grads[10], grads[11], (float *)rec(ms.dM, b), bb, kL, C, st));
+        if (logits_out) (void)hipMemcpyAsync(logits_out + (size_t)b * C, rec(ms.logits, b), C * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (site_logits_out) (void)hipMemcpyAsync(site_logits_out + (size_t)b * 2, rec(ms.slog, b), 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    }
+    // ---- per slide: pooling backward -> dP rows, the pooling gradient dH_pool rows (into the dZ2 buffer), dWc / dbc accumulated
+    for (int b = 0; b < B; ++b) {
+        const int64_t r0 = offsets[b], nb = offsets[b + 1] - r0;
+        TOAD_TRY(launch_pool_bwd(f.P + r0 * D2, f.P + r0 * D2 + D, D2, f.H + r0 * kL, p.wc, f.A_raw + r0 * kT, (float *)rec(ms.stats, b), (float *)rec(ms.M, b),
+                                 (float *)rec(ms.dM, b), nullptr, w.dP + r0 * D2, w.dP + r0 * D2 + D, D2, w.dZ2 + r0 * kL, grads[6], grads[7], b == 0 ? beta : 1.f,
+                                 nullptr, false, w.poolb_ws, w.poolb_ws_bytes, nb, kL, D, kT, drop_p, ds.sa + (uint64_t)b * G, ds.sb + (uint64_t)b * G, st));
+    }
+    // the slides' row ranges do not line up with the 256-row blocks of the concatenation: dP's abs-max array is measured in one pass
+    TOAD_TRY(launch_absmax(w.dP, D2, N, D2, w.amax_dP, false, st, what));
+    // ---- backward GEMMs over all rows
+    WgradDeferred dw[3];
+    TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what, TOAD_X_F32, &dw[0]));
+    // dZ2 = (dP Wab + dH_pool) * (H > 0), in place over the materialised dH_pool
+    TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, w.dZ2, f.H, nullptr, nopool, w.slabs,
+                          w.amax_dZ2, nullptr, st, what));
+    TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws2, st, what, TOAD_X_F32, &dw[1]));
+    TOAD_TRY(launch_nt_h2(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, f.bits_h1, nopool, w.slabs,
+                          w.amax_dZ1, nullptr, st, what));
+    TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, Xcat, f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws3, st, what, TOAD_X_F32, &dw[2]));
+    return launch_wgrad_reduce(dw, 3, st, what);
+}

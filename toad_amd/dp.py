@@ -66,6 +66,27 @@ def hip_slide_grad(model, grads: Dict[str, torch.Tensor], slide: Slide, beta: fl
     return loss
 
 
+def hip_batch_grad(model, grads: Dict[str, torch.Tensor], slides: Sequence[Slide], beta: float = 1.0, scale: float = 1.0,
+                   w_cls: float = 0.75, w_site: float = 0.25, xcat: Optional[torch.Tensor] = None, offsets=None):
+    """One library call for a whole shard of (small) slides: the trunk / attention GEMMs of forward and backward run once over the
+    concatenated bags, pooling / heads / loss per slide (toad_mil_multi_step_f32). grads = beta*grads + scale * sum_b d loss_b.
+    ``xcat`` / ``offsets``: the bags already concatenated on the device (an ingest buffer); else they are concatenated here.
+    Returns the per-slide loss vectors [B, 3]."""
+    from . import ops
+    from .model_toad import _draw_dropout
+    w = {k: v.detach() for k, v in model._weights().items()}
+    drop_p, seed = _draw_dropout(model._dropout and model.training)
+    sex = torch.cat([s[1].to(torch.float32).reshape(1) for s in slides])
+    label = torch.cat([s[2].reshape(1) for s in slides])
+    site = torch.cat([s[3].reshape(1) for s in slides])
+    if xcat is None:
+        bags = [s[0].float() if s[0].dtype != torch.float32 else s[0] for s in slides]
+        loss, _, _ = ops.mil_multi_step(w, grads, beta, bags, sex, label, site, w_cls * scale, w_site * scale, drop_p, seed)
+    else:
+        loss, _, _ = ops.mil_multi_step(w, grads, beta, xcat, sex, label, site, w_cls * scale, w_site * scale, drop_p, seed, offsets=offsets)
+    return loss
+
+
 class SlideShardedDP:
     def __init__(self, model, optimizer_factory: Callable[[Sequence[torch.nn.Parameter]], torch.optim.Optimizer],
                  process_group=None, slide_grad_fn: Optional[Callable] = None, broadcast_from: int = 0,
@@ -127,15 +148,40 @@ class SlideShardedDP:
             raise RuntimeError("SlideShardedDP: the model's flat parameter buffer was replaced after construction "
                                "(model.to()/deepcopy/re-flatten); build a new SlideShardedDP for the moved model")
 
-    def accumulate(self, slides: Sequence[Slide], global_slides: int, overwrite: bool = True):
+    # slides of at most this many patches are batched into one ragged multi-slide call, up to BATCH_ROWS rows per call
+    BATCH_MAX_PATCHES = 32768
+    BATCH_ROWS = 131072
+
+    def accumulate(self, slides: Sequence[Slide], global_slides: int, overwrite: bool = True, batched: Optional[bool] = None):
         """grads (+)= sum over ``slides`` of d(loss)/d(params) / global_slides. With ``overwrite`` the
-        first slide is written with beta = 0, which replaces a zeroing pass over the bucket."""
+        first slide is written with beta = 0, which replaces a zeroing pass over the bucket.
+        ``batched`` (default: when this rank holds several fp32 bags of at most BATCH_MAX_PATCHES patches and the default slide
+        function is in use): consecutive small slides go through ONE ragged multi-slide call per <= BATCH_ROWS rows
+        (hip_batch_grad): same gradient to fp32 round-off, a fraction of the launches."""
         self._check_flat()
         if not slides:
             if overwrite:
                 self.zero_grad()
             return []
         scale = 1.0 / float(global_slides)
+        small = lambda s: torch.is_tensor(s[0]) and 0 < s[0].shape[0] <= self.BATCH_MAX_PATCHES    # noqa: E731
+        if batched is None:
+            batched = self.slide_grad_fn is hip_slide_grad and len(slides) > 1 and sum(1 for s in slides if small(s)) > 1
+        if batched:
+            losses, first, i = [], True, 0
+            while i < len(slides):
+                j, rows = i, 0
+                while j < len(slides) and small(slides[j]) and rows + slides[j][0].shape[0] <= self.BATCH_ROWS:
+                    rows += slides[j][0].shape[0]; j += 1
+                beta = 0.0 if (overwrite and first) else 1.0
+                if j - i >= 2:
+                    lb = hip_batch_grad(self.model, self.grads, slides[i:j], beta, scale)
+                    losses.extend(lb[k] for k in range(j - i))
+                else:
+                    j = i + 1
+                    losses.append(self.slide_grad_fn(self.model, self.grads, slides[i], beta, scale))
+                first, i = False, j
+            return losses
         return [self.slide_grad_fn(self.model, self.grads, s, 0.0 if (overwrite and i == 0) else 1.0, scale)
                 for i, s in enumerate(slides)]
 

@@ -75,8 +75,8 @@ class _ScoresFn(torch.autograd.Function):
         # reuse the pooled backward with softmax weight p == 0 (stats = (0, inf)): dS = dA
         stats = torch.tensor([[0.0, float("inf")]] * t, device=dev)
         zeros = torch.zeros((t, l), device=dev)
-        if l not in (512, 1024):
-            raise NotImplementedError("Attn_Net_Gated backward supports L in {512, 1024}")
+        if l > 1024 or l % 8 or d > 512 or d % 4 or t > 4:
+            raise NotImplementedError("Attn_Net_Gated on the HIP kernels: L <= 1024 (multiple of 8), D <= 512 (multiple of 4), n_tasks <= 4")
         dp, _, dwc, dbc = ops.gated_pool_bwd(p, d, x, wc, torch.zeros((n, t), device=dev), stats, zeros, zeros,
                                              da.contiguous(), drop_p=ctx.drop[0], seed_a=ctx.drop[1], seed_b=ctx.drop[2])
         dwab, dbab = ops.linear_wgrad(dp, x)

@@ -502,6 +502,51 @@ def mil_step(w, grads, beta: float, bag, sex, label, site, w_cls: float = 0.75, 
     return loss, logits, slog
 
 
+def mil_multi_step(w, grads, beta: float, bags, sex, label, site, w_cls: float = 0.75, w_site: float = 0.25,
+                   drop_p: float = 0.0, seed: int = 0, want_logits: bool = False, offsets=None):
+    """forward + weighted CE + backward for a BATCH of slides in ONE library call (toad_mil_multi_step_f32): the trunk / attention GEMMs
+    run once over the concatenated bags, pooling + heads + loss per slide. ``bags``: a list of fp32 [N_b, 1024] device tensors
+    (concatenated here), or ONE already concatenated [sum N_b, 1024] tensor together with ``offsets`` (list of B + 1 row offsets).
+    ``sex`` [B] float32, ``label`` / ``site`` [B] int64 device tensors. grads = beta*grads + sum over the batch.
+    Returns (loss [B,3], logits [B,C] | None, site_logits [B,2] | None)."""
+    import ctypes
+    if offsets is None:
+        bags = [b.contiguous() for b in bags]
+        offsets = [0]
+        for b in bags:
+            offsets.append(offsets[-1] + int(b.shape[0]))
+        xcat = bags[0] if len(bags) == 1 else torch.cat(bags, 0)
+    else:
+        xcat = bags
+        offsets = [int(o) for o in offsets]
+    nb = len(offsets) - 1
+    _chk(xcat, "bags"); _chk(sex, "sex"); _chk(label, "label", dtype=torch.int64); _chk(site, "site", dtype=torch.int64)
+    if xcat.dim() != 2 or xcat.shape[0] != offsets[-1] or sex.numel() != nb or label.numel() != nb or site.numel() != nb:
+        raise ValueError("mil_multi_step: one sex / label / site entry per slide and offsets[-1] == rows of the concatenation")
+    ws_t = [w[k] for k in STEP_SLOTS]
+    gs_t = [grads[k] for k in STEP_SLOTS]
+    for k, t in zip(STEP_SLOTS, ws_t):
+        _chk(t, k)
+    for k, t in zip(STEP_SLOTS, gs_t):
+        _chk(t, "grad " + k)
+    n, c, d = _step_dims(w, xcat)
+    lib = _lib.load()
+    dev = xcat.device
+    nbytes = int(lib.toad_mil_multi_ws_bytes(n, nb, c, d))
+    if nbytes == 0:
+        raise ValueError(f"mil_multi_step: unsupported batch (rows {n}, slides {nb})")
+    ws = _ws(nbytes, dev, "step")
+    loss = torch.empty((nb, 3), dtype=torch.float32, device=dev)
+    logits = torch.empty((nb, c), dtype=torch.float32, device=dev) if want_logits else None
+    slog = torch.empty((nb, 2), dtype=torch.float32, device=dev) if want_logits else None
+    offs = (ctypes.c_int64 * (nb + 1))(*offsets)
+    with _timed("mil_multi_step"):
+        _lib.check(lib.toad_mil_multi_step_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(xcat), offs, nb, _p(sex), _p(label), _p(site),
+                                               float(w_cls), float(w_site), c, d, float(drop_p), int(seed), _p(loss), _p(logits), _p(slog),
+                                               _p(ws), ws.numel(), _stream()), "toad_mil_multi_step_f32")
+    return loss, logits, slog
+
+
 # ---- model(data, sex) and loss.backward() as one C call each (toad_mil_fwd_f32 / toad_mil_bwd_f32) ---------------------
 ARENA_SLOTS = ("h1", "h", "p", "a_raw", "stats", "m", "mcat", "logits", "y_prob", "y_hat", "site_logits", "site_prob", "site_hat",
                "x_amax", "h1_amax", "h_amax", "h1_bits", "h_bits")
