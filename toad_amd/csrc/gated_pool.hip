@@ -276,52 +276,64 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
 }
 
 // Merge G block partials: M[t,:] = sum_b exp(m_b - m) acc_b / l ; stats[t] = (m, l).
-// grid = T*L/8 blocks; block = 256 threads = 2 float4 columns x 128 partial slices. Every block
-// recomputes the (tiny) global max / sum of its task; exp2(-inf) = 0 makes empty partials vanish
-// without a branch.
+// grid = T * ceil(L/32) blocks; block = 256 threads = 8 float4 column groups (32 columns) x 32 partial slices. Every block recomputes
+// the (tiny) global max / sum of its task; exp2(-inf) = 0 makes empty partials vanish without a branch. The launch is a chain of
+// dependent steps (max -> sum -> weighted accumulation -> store), so each step is as short as it can be made: wave reductions by
+// shuffles and ONE LDS exchange between the four waves instead of eight-step LDS trees and a serial 128-term tail (round 2's version:
+// 8.3 us; the pooling forward it finishes streams its 512.8 MB in 75 us, so every microsecond here is 1 % of the op).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 __global__ __launch_bounds__(256) void gated_pool_combine_kernel(const float *__restrict__ partials, int G, int L,
                                                                   int T, float *__restrict__ M,
                                                                   float *__restrict__ stats) {
-    __shared__ float red[256];
-    __shared__ __attribute__((aligned(16))) float sacc[128][8];
-    const int tid = threadIdx.x;
+    __shared__ float red[2][4];
+    __shared__ __attribute__((aligned(16))) float sacc[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t rec = pool_partial_floats(L, T);
-    const int blocks_per_t = L / 8;
-    const int t = blockIdx.x / blocks_per_t, col0 = (blockIdx.x % blocks_per_t) * 8;
+    const int blocks_per_t = (L + 31) / 32;
+    const int t = blockIdx.x / blocks_per_t, col0 = (blockIdx.x % blocks_per_t) * 32;
     const float *ml = partials + T * L + 2 * t;
 
-    float mx = -INFINITY;
-    for (int b = tid; b < G; b += 256) mx = __builtin_fmaxf(mx, ml[b * rec]);
-    red[tid] = mx;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] = __builtin_fmaxf(red[tid], red[tid + s]);
-        __syncthreads();
+    // the partial (max, sum) pairs this thread owns, loaded once (G <= 512 -> at most 2 per thread; more are re-read below)
+    float pm[2], pl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int b = tid + 256 * i;
+        pm[i] = b < G ? ml[b * rec] : -INFINITY;
+        pl[i] = b < G ? ml[b * rec + 1] : 0.f;
     }
-    mx = red[0];
+    float mx = __builtin_fmaxf(pm[0], pm[1]);
+    for (int b = tid + 512; b < G; b += 256) mx = __builtin_fmaxf(mx, ml[b * rec]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[0][wave] = mx;
     __syncthreads();
-    float ls = 0.f;
-    for (int b = tid; b < G; b += 256) ls += ml[b * rec + 1] * fast_exp(ml[b * rec] - mx);
-    red[tid] = ls;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-    }
-    ls = red[0];
-
-    const int q = tid & 1, slice = tid >> 1;
+    mx = __builtin_fmaxf(__builtin_fmaxf(red[0][0], red[0][1]), __builtin_fmaxf(red[0][2], red[0][3]));
+    float ls = pl[0] * fast_exp(pm[0] - mx) + pl[1] * fast_exp(pm[1] - mx);
+    for (int b = tid + 512; b < G; b += 256) ls += ml[b * rec + 1] * fast_exp(ml[b * rec] - mx);
+    ls = wave_sum(ls);
+    if (lane == 0) red[1][wave] = ls;
+    // weighted accumulation: thread (q = float4 group, slice) sums partials slice, slice + 32, ...
+    const int q = tid & 7, slice = tid >> 3;
+    const bool cok = col0 + q * 4 < L;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int b = slice; b < G; b += 128)
-        a += fast_exp(ml[b * rec] - mx) * ld4(partials + b * rec + t * L + col0 + q * 4);
-    st4(&sacc[slice][q * 4], a);
-    __syncthreads();
-    if (tid < 8) {
-        float v = 0.f;
-#pragma unroll 8
-        for (int s = 0; s < 128; ++s) v += sacc[s][tid];
-        M[t * L + col0 + tid] = v / ls;
+    if (cok) {
+        for (int b = slice; b < G; b += 32)
+            a += fast_exp(ml[b * rec] - mx) * ld4(partials + b * rec + t * L + col0 + q * 4);
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {            // sum the 8 slices of this wave that share q (lane bits 3..5), fixed order
+        a[e] += __shfl_xor(a[e], 8);
+        a[e] += __shfl_xor(a[e], 16);
+        a[e] += __shfl_xor(a[e], 32);
+    }
+    if (lane < 8) st4(&sacc[wave][q * 4], a);
+    __syncthreads();
+    ls = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    if (tid < 32 && col0 + tid < L) M[t * L + col0 + tid] = ((sacc[0][tid] + sacc[1][tid]) + (sacc[2][tid] + sacc[3][tid])) / ls;
     if (blockIdx.x % blocks_per_t == 0 && tid == 0) {
         stats[2 * t] = mx;
         stats[2 * t + 1] = ls;
@@ -669,7 +681,7 @@ extern "C" int toad_gated_pool_fwd_f32(const float *Pa, const float *Pb, int64_t
     launch_fwd<true>(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, bc, A_raw, (float *)ws, (int)N, da, db);
     int rc = check_launch(what);
     if (rc) return rc;
-    hipLaunchKernelGGL(gated_pool_combine_kernel, dim3(T * L / 8), dim3(256), 0, st, (const float *)ws, grid, L, T, M, stats);
+    hipLaunchKernelGGL(gated_pool_combine_kernel, dim3(T * ((L + 31) / 32)), dim3(256), 0, st, (const float *)ws, grid, L, T, M, stats);
     return check_launch(what);
 }
 

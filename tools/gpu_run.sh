@@ -3,6 +3,7 @@
 #   tests[:expr]  pytest -m gpu (optionally -k expr or a file list after ':')      bench[:args]  bench.py (no CPU baseline unless args say so)
 #   ab:N          tools/ab_step.py on prepared and fp32 bags                         stats[:N]     rocprofv3 --kernel-trace --stats of the fused step
 #   pmc[:N]       SQ counter pass of the fused step                                  smoke         __graft_entry__.smoke()
+#   traffic[:N]   FETCH_SIZE / WRITE_SIZE passes of the pool kernels -> pool_traffic.json (copy to profiles/rNN_pool_traffic.json)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-run}; shift
@@ -31,6 +32,12 @@ for what in "$@"; do
       (cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE \
           --kernel-trace --output-format csv -d $OUT/pmc -o p -- python $ROOT/tools/pmc_step.py ${arg:-100000} 3 > $OUT/pmc.log 2>&1)
       python tools/pmc_table.py $(dirname $(find $OUT/pmc -name "*counter_collection.csv" | head -1)) > $OUT/pmc_step.txt 2>&1; head -30 $OUT/pmc_step.txt ;;
+    traffic)        # HBM traffic of the pool kernels: separate FETCH_SIZE / WRITE_SIZE passes (one pass with both aborts on gfx950)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        (cd /tmp && timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/traffic/$c -o p -- python $ROOT/tools/pmc_pool.py ${arg:-100000} > $OUT/traffic_$c.log 2>&1)
+        find $OUT/traffic/$c -name "*.db" -delete
+      done
+      python tools/pool_traffic_json.py $OUT/traffic ${arg:-100000} > $OUT/pool_traffic.json 2> $OUT/pool_traffic.err; cat $OUT/pool_traffic.json | head -40; tail -3 $OUT/pool_traffic.err ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
     *) echo "unknown job $what" ;;
