@@ -11,7 +11,7 @@ model) in chunks of `--chunk`, assembles the [tiles,1024] bag on the device, and
 
   roofline      the extractor's GEMMs: 8.556 GFLOP per tile (43 convolutions as NHWC GEMMs) over
                 the HIP-event time of the extractor calls inside the timed steps, against the fp32-equivalent MFMA
-                ceiling of the split-bf16 kernel (dense bf16 peak / 6 = 416.7 TFLOP/s);
+                ceiling of the fp16 two-piece arithmetic every one of them runs since round 3 (dense fp16 peak / 3 = 833.3 TFLOP/s);
   cpu_baseline  the CPU oracle of the extractor (oracle/resnet_oracle.py = the reference's op sequence on torch CPU,
                 pinned to the reference) on a bounded sample of tiles on this box's host cores.
 """
@@ -139,14 +139,15 @@ def main():
         tf = FLOP_PER_TILE * n / (ext_ms * 1e-3)
         out = {"metric": "patches/sec end-to-end: 256x256 tiles -> ResNet50-trunc -> bag -> attention-MIL step", "value": round(n * world * args.steps / elapsed, 1),
                "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (storage + accumulation; GEMM operands as 2 x f16 pieces, 3 MFMA terms)", "data": "synthetic",
                "config": {"workload": f"{n} N(0,1) tiles 3x256x256 per GPU per step (resident in HBM) -> resnet50_baseline (random init, eval-BN folded) "
                                       f"in chunks of {chunk} -> bag [{n},1024] -> TOAD_fc_mtl_concat(big, 18 classes) fwd + CE + bwd + Adam",
-                          "arithmetic": "fp32 storage/accumulation; conv-as-GEMM products as split-bf16 (6 MFMA terms) = fp32-equivalent",
+                          "arithmetic": "fp32 storage/accumulation; conv-as-GEMM operands as two fp16 pieces (3 MFMA terms, one tensor-wide power-of-two "
+                                        "scale per activation from producer-emitted abs-max scalars, per-row scales for the weights) = fp32-equivalent",
                           "parallelism": f"slide-sharded dp{world}"},
-               "roofline": {"bound": "mfma", "kernel": "43 conv-as-GEMM launches per chunk: gemm_nt_split_narrow_kernel<2,2|1,4> (Cout <= 128, implicit 3x3 gather) + gemm_nt_split_big_kernel (Cout >= 256); + stem/strided gathers, pools",
+               "roofline": {"bound": "mfma", "kernel": "43 conv-as-GEMM launches per chunk: gemm_nt_h2_narrow_kernel<2,2|1,4> (Cout <= 128 and short-K residual GEMMs, implicit 3x3 / stem gather) + gemm_nt_h2_big_kernel (Cout >= 256); + strided gathers, pools",
                             "achieved": round(tf / 1e12, 2), "peak": round(MFMA_EQ_PEAK / 1e12, 1), "unit": "TFLOP/s fp32-equivalent",
-                            "frac": round(tf / MFMA_EQ_PEAK, 4), "traffic": None, "bf16_mfma_tflops_issued": round(tf * SPLIT_TERMS / 1e12, 1),
+                            "frac": round(tf / MFMA_EQ_PEAK, 4), "traffic": None, "fp16_mfma_tflops_issued": round(tf * SPLIT_TERMS / 1e12, 1),
                             "algorithmic_flops": FLOP_PER_TILE * n, "extractor_ms_per_step": round(ext_ms, 3),
                             "extractor_share_of_step": round(ext_ms / ms, 4)},
                "last_loss": round(float(losses[-1][0].item()) * world, 5)}

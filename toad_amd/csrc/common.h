@@ -104,13 +104,22 @@ int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax,
 int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C,
                  int64_t ldc, int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
                  const float *mask_src, const unsigned long long *mask_bits, H2Pool pool, float *slabs, float *y_amax,
-                 unsigned long long *bits_out, hipStream_t st, const char *what, int a_mode = TOAD_X_F32);
+                 unsigned long long *bits_out, hipStream_t st, const char *what, int a_mode = TOAD_X_F32, int a_stride = 1, int y_stride = 1);
 size_t pt_bytes_host(int64_t rows, int64_t cols);                                                          // bytes of a plane-tiled tensor
 int launch_pt_split(const float *X, int64_t ld, int64_t M, int64_t K, const float *amax, unsigned short *pt, hipStream_t st, const char *what);
 int launch_pool_bwd(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *A_raw, const float *stats,
                     const float *M, const float *dM, const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH, float *dWc, float *dbc,
                     float beta, float *dp_amax, bool zero_amax, void *ws, size_t ws_bytes, int64_t N, int L, int D, int T, float drop_p,
                     uint64_t seed_a, uint64_t seed_b, hipStream_t st);
+// the extractor's GEMMs with tensor-wide abs-max scalars threaded from producer to consumer (gemm_f32.hip; used by conv.hip)
+int launch_gmax(const float *x, int64_t n, float *out, hipStream_t st, const char *what);                   // out[0] = max |x| (zeroed here)
+int ext_linear(const float *X, const float *x_gmax, const float *W, const float *bias, const float *residual, float *Y, float *y_gmax,
+               int64_t M, int64_t K, int64_t N, int act, void *ws, size_t ws_bytes, hipStream_t st, const char *what);
+int ext_conv_nhwc(const float *X, const float *x_gmax, const float *Wf, const float *bias, const float *residual, float *Y, float *y_gmax, int B,
+                  int H, int W, int Cin, int kh, int kw, int stride, int pad, int Cout, int act, void *ws, size_t ws_bytes, hipStream_t st,
+                  const char *what);
+int ext_stem_conv(const float *Xs, const float *x_gmax, const float *Wf, const float *bias, float *Y, float *y_gmax, int B, int Ho, int Wo, int act,
+                  void *ws, size_t ws_bytes, hipStream_t st, const char *what);
 struct WgradDeferred;
 int launch_wgrad(const float *dY, const float *dy_amax, const float *X, const float *x_amax, float *dW, float *db, int64_t M,
                  int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what, int x_mode = TOAD_X_F32,

@@ -253,7 +253,7 @@ extern "C" int toad_avgpool_nhwc_f32(const float *X, float *feat, int B, int HW,
 extern "C" size_t toad_resnet50_trunc_ws_bytes(int B, int H, int W) {
     NetPlan p;
     if (!make_plan(B, H, W, p)) return 0;
-    return 4 * align2m(p.act_max * 4) + align2m(p.cols_max * 4) + align2m(p.gemm_ws) + ((size_t)1 << 21);
+    return 4 * align2m(p.act_max * 4) + align2m(p.cols_max * 4) + align2m(p.gemm_ws) + align2m(4096) + ((size_t)1 << 21);
 }
 
 // weights[i] : folded conv i as [Cout, K] fp32 (K = kh*kw*Cin in (ky, kx, c) order; the stem is [64, 192] in the space-to-depth
@@ -277,13 +277,24 @@ extern "C" int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float 
     float *cols = reinterpret_cast<float *>(take(p.cols_max * 4));
     void *gws = take(p.gemm_ws);
     const size_t gcap = p.gemm_ws;
+    // Tensor-wide abs-max scalars, one per activation the network produces (round 3): every GEMM epilogue maxes |output| into the slot of
+    // its output, the consumer derives ONE power-of-two scale for its fp16 two-piece A operand from it (gemm_narrow.inc). Pools and the
+    // im2col / space-to-depth gathers only move values (plus zeros), so their outputs share the producer's slot. All slots are zeroed
+    // by one memset; nothing in the call measures an activation a second time.
+    float *gm = reinterpret_cast<float *>(take(4096));
+    (void)hipMemsetAsync(gm, 0, 4096, st);
+    int gi = 0;
+    auto slot = [&]() { return gm + (gi++); };
     int rc;
 #define TOAD_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
     // stem: 7x7/2 conv + BN + ReLU (resnet_custom.py:96-98), 3x3/2 max-pool (:99)
+    float *g_in = slot();
+    TOAD_TRY(launch_gmax(tiles_nchw, (int64_t)B * 3 * H * W, g_in, st, what));      // the only measured tensor: the caller's tiles
     TOAD_TRY(toad_stem_s2d_nchw_f32(tiles_nchw, cols, B, H, W, st));              // 12-channel space-to-depth image (53 MB per 64 tiles)
-    TOAD_TRY(toad_stem_conv_s2d_f32(cols, weights[0], biases[0], act[0], B, p.Hs, p.Ws, TOAD_ACT_RELU, gws, gcap, st));
-    TOAD_TRY(toad_maxpool3x3s2_nhwc_f32(act[0], act[1], B, p.Hs, p.Ws, 64, st));
-    float *x = act[1];                          // block input
+    float *gx = slot();
+    TOAD_TRY(ext_stem_conv(cols, g_in, weights[0], biases[0], act[0], gx, B, p.Hs, p.Ws, TOAD_ACT_RELU, gws, gcap, st, what));
+    TOAD_TRY(toad_maxpool3x3s2_nhwc_f32(act[0], act[1], B, p.Hs, p.Ws, 64, st));      // max-pooling keeps the maximum: same slot
+    float *x = act[1];                          // block input (abs-max scalar: gx)
     auto other = [&](float *a0, float *a1, float *a2) {          // a buffer different from the (up to) three in use
         for (int i = 0; i < 4; ++i) if (act[i] != a0 && act[i] != a1 && act[i] != a2) return act[i];
         return (float *)nullptr;
@@ -296,18 +307,20 @@ extern "C" int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float 
             const int64_t Mi = (int64_t)B * h * w, Mo = (int64_t)B * ho * wo;
             float *t1 = other(x, nullptr, nullptr);
             // conv1 1x1 + BN + ReLU (:38-40): cols == x
-            TOAD_TRY(toad_linear_act_res_fwd_f32(x, weights[ci], biases[ci], nullptr, t1, Mi, inpl, pl, TOAD_ACT_RELU, gws, gcap, st));
+            float *g1 = slot();
+            TOAD_TRY(ext_linear(x, gx, weights[ci], biases[ci], nullptr, t1, g1, Mi, inpl, pl, TOAD_ACT_RELU, gws, gcap, st, what));
             // conv2 3x3 stride s + BN + ReLU (:42-44)
             float *t2 = other(x, t1, nullptr);
             // gather inside the GEMM's LDS-DMA, no cols buffer: always for the narrow layers; for 256 output channels (two
             // 128-column tiles per 256 rows, A gathered and split twice) only when there are enough tiles to fill the chip
             // twice over - otherwise im2col + the 256x256 kernel with its K-split is faster (measured at B = 64 vs 512)
             const bool implicit = implicit_conv_enabled() && (pl <= 128 || (pl <= 256 && (Mo / 256) * ((pl + 127) / 128) >= 512));
+            float *g2 = slot();
             if (implicit) {
-                TOAD_TRY(toad_conv_nhwc_f32(t1, weights[ci + 1], biases[ci + 1], nullptr, t2, B, h, w, pl, 3, 3, s, 1, pl, TOAD_ACT_RELU, gws, gcap, st));
+                TOAD_TRY(ext_conv_nhwc(t1, g1, weights[ci + 1], biases[ci + 1], nullptr, t2, g2, B, h, w, pl, 3, 3, s, 1, pl, TOAD_ACT_RELU, gws, gcap, st, what));
             } else {
                 TOAD_TRY(toad_im2col_nhwc_f32(t1, cols, B, h, w, pl, 3, 3, s, 1, st));
-                TOAD_TRY(toad_linear_act_res_fwd_f32(cols, weights[ci + 1], biases[ci + 1], nullptr, t2, Mo, 9 * pl, pl, TOAD_ACT_RELU, gws, gcap, st));
+                TOAD_TRY(ext_linear(cols, g1, weights[ci + 1], biases[ci + 1], nullptr, t2, g2, Mo, 9 * pl, pl, TOAD_ACT_RELU, gws, gcap, st, what));
             }
             // residual: identity, or downsample = strided 1x1 conv + BN (:49-50, :79-85)
             const float *res = x;
@@ -316,14 +329,15 @@ extern "C" int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float 
                 rbuf = t1;                       // t1 is dead once conv2 has consumed it
                 const float *src = x;
                 if (s != 1) { TOAD_TRY(toad_im2col_nhwc_f32(x, cols, B, h, w, inpl, 1, 1, s, 0, st)); src = cols; }
-                TOAD_TRY(toad_linear_act_res_fwd_f32(src, weights[ci + 3], biases[ci + 3], nullptr, rbuf, Mo, inpl, 4 * pl, TOAD_ACT_NONE, gws, gcap, st));
-                res = rbuf;
+                TOAD_TRY(ext_linear(src, gx, weights[ci + 3], biases[ci + 3], nullptr, rbuf, nullptr, Mo, inpl, 4 * pl, TOAD_ACT_NONE, gws, gcap, st, what));
+                res = rbuf;                      // (only ever an epilogue addend: nobody needs its abs-max)
             }
             // conv3 1x1 + BN, + residual, ReLU (:46-47, :52-53) in one epilogue
             float *y = other(x, t2, rbuf);
-            TOAD_TRY(toad_linear_act_res_fwd_f32(t2, weights[ci + 2], biases[ci + 2], res, y, Mo, pl, 4 * pl, TOAD_ACT_RELU, gws, gcap, st));
+            float *gy = slot();
+            TOAD_TRY(ext_linear(t2, g2, weights[ci + 2], biases[ci + 2], res, y, gy, Mo, pl, 4 * pl, TOAD_ACT_RELU, gws, gcap, st, what));
             ci += b == 0 ? 4 : 3;
-            x = y; inpl = 4 * pl; h = ho; w = wo;
+            x = y; gx = gy; inpl = 4 * pl; h = ho; w = wo;
         }
 #undef TOAD_TRY
     return toad_avgpool_nhwc_f32(x, feat, B, h * w, inpl, st);

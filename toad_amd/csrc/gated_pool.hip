@@ -277,10 +277,12 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
 
 // Merge G block partials: M[t,:] = sum_b exp(m_b - m) acc_b / l ; stats[t] = (m, l).
 // grid = T * ceil(L/32) blocks; block = 256 threads = 8 float4 column groups (32 columns) x 32 partial slices. Every block recomputes
-// the (tiny) global max / sum of its task; exp2(-inf) = 0 makes empty partials vanish without a branch. The launch is a chain of
-// dependent steps (max -> sum -> weighted accumulation -> store), so each step is as short as it can be made: wave reductions by
-// shuffles and ONE LDS exchange between the four waves instead of eight-step LDS trees and a serial 128-term tail (round 2's version:
-// 8.3 us; the pooling forward it finishes streams its 512.8 MB in 75 us, so every microsecond here is 1 % of the op).
+// the (tiny) global max / sum of its task; exp2(-inf) = 0 makes empty partials vanish without a branch. The launch is latency: a chain
+// of dependent steps (max -> weights -> weighted accumulation -> store). Here ALL global loads of a thread - its (max, sum) pairs and
+// the 16 partial rows of its columns - are issued up front in one round trip (the rows do not depend on the maximum, only their
+// weights do; those go through LDS), and the reductions are wave shuffles plus one LDS exchange between the four waves instead of
+// eight-step LDS trees and a serial 128-term tail. The pooling forward this kernel finishes streams its 512.8 MB in 75 us, so every
+// microsecond here is 1 % of the op.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -290,20 +292,30 @@ __global__ __launch_bounds__(256) void gated_pool_combine_kernel(const float *__
                                                                   int T, float *__restrict__ M,
                                                                   float *__restrict__ stats) {
     __shared__ float red[2][4];
+    __shared__ float wgt[512];                       // exp(m_b - m) of the first 512 partials (the launch grid of the forward is capped there)
     __shared__ __attribute__((aligned(16))) float sacc[4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t rec = pool_partial_floats(L, T);
     const int blocks_per_t = (L + 31) / 32;
     const int t = blockIdx.x / blocks_per_t, col0 = (blockIdx.x % blocks_per_t) * 32;
     const float *ml = partials + T * L + 2 * t;
+    const int q = tid & 7, slice = tid >> 3;
+    const bool cok = col0 + q * 4 < L;
+    const float *pcol = partials + t * L + col0 + q * 4;
 
-    // the partial (max, sum) pairs this thread owns, loaded once (G <= 512 -> at most 2 per thread; more are re-read below)
+    // round trip 1: the (max, sum) pairs this thread owns AND - they do not depend on them - the first 16 partial rows of its columns
     float pm[2], pl[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int b = tid + 256 * i;
         pm[i] = b < G ? ml[b * rec] : -INFINITY;
         pl[i] = b < G ? ml[b * rec + 1] : 0.f;
+    }
+    f32x4 pv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int b = slice + 32 * i;
+        pv[i] = (cok && b < G) ? ld4(pcol + b * rec) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float mx = __builtin_fmaxf(pm[0], pm[1]);
     for (int b = tid + 512; b < G; b += 256) mx = __builtin_fmaxf(mx, ml[b * rec]);
@@ -312,17 +324,19 @@ __global__ __launch_bounds__(256) void gated_pool_combine_kernel(const float *__
     if (lane == 0) red[0][wave] = mx;
     __syncthreads();
     mx = __builtin_fmaxf(__builtin_fmaxf(red[0][0], red[0][1]), __builtin_fmaxf(red[0][2], red[0][3]));
-    float ls = pl[0] * fast_exp(pm[0] - mx) + pl[1] * fast_exp(pm[1] - mx);
+    const float w0 = fast_exp(pm[0] - mx), w1 = fast_exp(pm[1] - mx);
+    wgt[tid] = w0; wgt[tid + 256] = w1;
+    float ls = pl[0] * w0 + pl[1] * w1;
     for (int b = tid + 512; b < G; b += 256) ls += ml[b * rec + 1] * fast_exp(ml[b * rec] - mx);
     ls = wave_sum(ls);
     if (lane == 0) red[1][wave] = ls;
-    // weighted accumulation: thread (q = float4 group, slice) sums partials slice, slice + 32, ...
-    const int q = tid & 7, slice = tid >> 3;
-    const bool cok = col0 + q * 4 < L;
+    __syncthreads();
+    // weighted accumulation in a fixed order: partials slice, slice + 32, ... (all already in registers)
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a += wgt[slice + 32 * i] * pv[i];
     if (cok) {
-        for (int b = slice; b < G; b += 32)
-            a += fast_exp(ml[b * rec] - mx) * ld4(partials + b * rec + t * L + col0 + q * 4);
+        for (int b = slice + 512; b < G; b += 32) a += fast_exp(ml[b * rec] - mx) * ld4(pcol + b * rec);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {            // sum the 8 slices of this wave that share q (lane bits 3..5), fixed order
@@ -331,8 +345,8 @@ __global__ __launch_bounds__(256) void gated_pool_combine_kernel(const float *__
         a[e] += __shfl_xor(a[e], 32);
     }
     if (lane < 8) st4(&sacc[wave][q * 4], a);
-    __syncthreads();
     ls = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    __syncthreads();
     if (tid < 32 && col0 + tid < L) M[t * L + col0 + tid] = ((sacc[0][tid] + sacc[1][tid]) + (sacc[2][tid] + sacc[3][tid])) / ls;
     if (blockIdx.x % blocks_per_t == 0 && tid == 0) {
         stats[2 * t] = mx;
