@@ -38,6 +38,10 @@ for what in "$@"; do
         find $OUT/traffic/$c -name "*.db" -delete
       done
       python tools/pool_traffic_json.py $OUT/traffic ${arg:-100000} > $OUT/pool_traffic.json 2> $OUT/pool_traffic.err; cat $OUT/pool_traffic.json | head -40; tail -3 $OUT/pool_traffic.err ;;
+    xstats)         # rocprofv3 kernel stats of the extractor alone (B tiles per call)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/xprof -o p -- python $ROOT/tools/extractor_bench.py ${arg:-512} 4 > $OUT/xprof.log 2>&1)
+      python tools/summarize_rocprof.py $(find $OUT/xprof -name "*kernel_stats.csv" | head -1) "$TAG extractor, ${arg:-512} tiles per call" > $OUT/extractor_kernel_stats.md 2>&1
+      head -24 $OUT/extractor_kernel_stats.md; tail -2 $OUT/xprof.log ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
     *) echo "unknown job $what" ;;
