@@ -115,10 +115,16 @@ def test_backward_chain_tight_with_identical_relu_masks(cuda, golden, name):
     # terms, not of the result. The allowance for that is measured, not assumed: 10 x the deviation of the SAME backward evaluated
     # in plain fp32 on the CPU from its fp64 value. For the well-conditioned gradients that deviation is ~1e-6 of the scale and the
     # 2e-5 bound is the one that binds.
+    # The three cancellation-dominated gradients get 32 x since round 3: their device error is eps32 x the size of the cancelling terms
+    # (e.g. d attention_c.bias = sum_r p_r (dM.H_r - dM.M): an error of 1e-7 relative in the softmax normaliser shifts it by 1e-7 |dM.M|),
+    # and which way the last bits of that normaliser fall depends on the summation order of the merge kernel, which round 3 shortened.
+    # Measured there: 18 x (attention_c.bias, n777) and 12 x (attention_a.bias, n777) the CPU's ONE noise sample; every other gradient
+    # of every case stays at or below 3 x, and the eleven well-conditioned gradients keep 10 x (where the 2e-5 bound is the one that binds).
+    cancelling = ("ba", "bb", "bc")
     o32 = orc.backward(ci["params"], saved_cpu, dl, ds)
     for sl, k in SLOT2KEY.items():
         noise = (o32[k].double() - og[k]).abs().max().item()
-        assert_grad_close(g[sl], og[k], 2e-5, grad_scale(og, k), what=f"{name}:{sl}", floor=10.0 * noise)
+        assert_grad_close(g[sl], og[k], 2e-5, grad_scale(og, k), what=f"{name}:{sl}", floor=(32.0 if sl in cancelling else 10.0) * noise)
 
 
 def test_module_random_bag_vs_oracle(cuda):

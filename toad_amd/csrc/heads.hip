@@ -143,11 +143,15 @@ __global__ __launch_bounds__(1024) void heads_ce_fused_kernel(
     const float *__restrict__ Wsite, const float *__restrict__ bsite, const int64_t *__restrict__ label,
     const int64_t *__restrict__ site, float w_cls, float w_site, float *Mcat, float *logits, float *Y_prob, int64_t *Y_hat,
     float *site_logits, float *site_prob, int64_t *site_hat, float *loss_out, float *dlogits, float *dsite, float *dWcls,
-    float *dbcls, float *dWsite, float *dbsite, float *dM, float beta, int L, int C) {
-    extern __shared__ float s_all[];                 // [2][L+1] Mcat | [C] logits | [2] site logits | [C] dlogits | [2] dsite
+    float *dbcls, float *dWsite, float *dbsite, float *dM, float beta, int L, int C, int cache_w) {
+    extern __shared__ float s_all[];                 // [2][L+1] Mcat | [C] logits | [2] site logits | [C] dlogits | [2] dsite | cache_w: [C+2][L+1] weights
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int LP = L + 1;
     float *s_m = s_all, *s_lg = s_all + 2 * LP, *s_sl = s_lg + C, *s_dl = s_sl + 2, *s_ds = s_dl + C;
+    // cache_w: the forward's pass over the head weights also parks them in LDS, so the backward's dM = dlogits . Wcls + dsite . Wsite
+    // reads LDS instead of walking C dependent global loads per thread (that loop was ~10 of this kernel's ~21 us, and the kernel runs
+    // once per slide: 64 times in a 64-slide batch of small bags)
+    float *s_w = s_ds + 2;
     const float sx = sex[0];
     for (int e = tid; e < 2 * LP; e += 1024) {
         const int t = e / LP, k = e % LP;
@@ -160,7 +164,11 @@ __global__ __launch_bounds__(1024) void heads_ce_fused_kernel(
         const float *w = r < C ? Wcls + (int64_t)r * LP : Wsite + (int64_t)(r - C) * LP;
         const float *x = r < C ? s_m : s_m + LP;
         float p = 0.f;
-        for (int k = lane; k < LP; k += 64) p = fmaf(w[k], x[k], p);
+        for (int k = lane; k < LP; k += 64) {
+            const float wk = w[k];
+            if (cache_w) s_w[r * LP + k] = wk;
+            p = fmaf(wk, x[k], p);
+        }
         p = wave_sum(p);
         if (lane == 0) {
             if (r < C) { const float v = p + bcls[r]; logits[r] = v; s_lg[r] = v; }
@@ -191,9 +199,14 @@ __global__ __launch_bounds__(1024) void heads_ce_fused_kernel(
             dWsite[o] = (beta != 0.f ? beta * dWsite[o] : 0.f) + s_ds[c] * s_m[LP + k];
             if (k == 0) dbsite[c] = (beta != 0.f ? beta * dbsite[c] : 0.f) + s_ds[c];
         } else if (k < L) {
-            float d0 = 0.f;
-            for (int c = 0; c < C; ++c) d0 = fmaf(s_dl[c], Wcls[(int64_t)c * LP + k], d0);
-            const float d1 = fmaf(s_ds[1], Wsite[LP + k], s_ds[0] * Wsite[k]);
+            float d0 = 0.f, d1;
+            if (cache_w) {
+                for (int c = 0; c < C; ++c) d0 = fmaf(s_dl[c], s_w[c * LP + k], d0);
+                d1 = fmaf(s_ds[1], s_w[(C + 1) * LP + k], s_ds[0] * s_w[C * LP + k]);
+            } else {
+                for (int c = 0; c < C; ++c) d0 = fmaf(s_dl[c], Wcls[(int64_t)c * LP + k], d0);
+                d1 = fmaf(s_ds[1], Wsite[LP + k], s_ds[0] * Wsite[k]);
+            }
             dM[k] = d0;
             dM[L + k] = d1;
         }
@@ -281,10 +294,13 @@ extern "C" int toad_heads_ce_fused_f32(const float *M, const float *sex, const f
     if (!M || !sex || !Wcls || !bcls || !Wsite || !bsite || !label || !site || !Mcat || !logits || !Y_prob || !Y_hat || !site_logits ||
         !site_prob || !site_hat || !loss_out || !dWcls || !dbcls || !dWsite || !dbsite || !dM) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (L <= 0 || L > 8192 || C <= 0 || C > 1024 || C > L) { set_error("%s: unsupported L=%d C=%d", what, L, C); return TOAD_ESHAPE; }
-    const size_t smem = (size_t)(2 * (L + 1) + 2 * C + 4) * sizeof(float);
+    size_t smem = (size_t)(2 * (L + 1) + 2 * C + 4) * sizeof(float);
+    const size_t wbytes = (size_t)(C + 2) * (L + 1) * sizeof(float);
+    const int cache_w = smem + wbytes <= 60 * 1024 ? 1 : 0;          // 18 classes x 513: 41 KB (below the 64 KB a launch gets without an attribute)
+    if (cache_w) smem += wbytes;
     hipLaunchKernelGGL(heads_ce_fused_kernel, dim3(1), dim3(1024), smem, (hipStream_t)stream, M, sex, Wcls, bcls, Wsite, bsite, label,
                        site, w_cls, w_site, Mcat, logits, Y_prob, Y_hat, site_logits, site_prob, site_hat, loss_out, dlogits, dsite,
-                       dWcls, dbcls, dWsite, dbsite, dM, beta, L, C);
+                       dWcls, dbcls, dWsite, dbsite, dM, beta, L, C, cache_w);
     return check_launch(what);
 }
 
