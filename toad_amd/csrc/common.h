@@ -120,6 +120,22 @@ int ext_conv_nhwc(const float *X, const float *x_gmax, const float *Wf, const fl
                   const char *what);
 int ext_stem_conv(const float *Xs, const float *x_gmax, const float *Wf, const float *bias, float *Y, float *y_gmax, int B, int Ho, int Wo, int act,
                   void *ws, size_t ws_bytes, hipStream_t st, const char *what);
+// batched pooling launches of the ragged multi-slide step (gated_pool.hip): blockIdx.y = slide, row ranges from the DEVICE array seg_dev [B+1]
+size_t pool_batch_ws_bytes(int B, int L, int D, int T);
+int launch_pool_fwd_batch(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *bc, float *A_raw, float *M,
+                          int m_stride, float *stats, int s_stride, void *ws, const int64_t *seg_dev, int B, int64_t max_n, int L, int D, int T,
+                          float drop_p, uint64_t seed_a, uint64_t seed_b, hipStream_t st);
+int launch_pool_bwd_batch(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *A_raw, const float *stats,
+                          int s_stride, const float *M, const float *dM, int m_stride, float *dPa, float *dPb, int64_t ldd, float *dH, float *dWc,
+                          float *dbc, float beta, void *ws, const int64_t *seg_dev, int B, int64_t max_n, int L, int D, int T, float drop_p,
+                          uint64_t seed_a, uint64_t seed_b, hipStream_t st);
+// batched heads + weighted CE + heads backward of the ragged multi-slide step (heads.hip): one workgroup per slide, then the head-weight gradients
+struct HeadsBatch {          // per-slide records, all with the same byte stride `rec` (slide b of array p: (char *)p + b * rec)
+    const float *M; float *Mcat, *logits, *yprob; int64_t *yhat; float *slog, *sprob; int64_t *shat; float *dM, *dl, *ds; size_t rec;
+};
+int launch_heads_batch(const HeadsBatch &hb, const float *sex, const float *Wcls, const float *bcls, const float *Wsite, const float *bsite,
+                       const int64_t *label, const int64_t *site, float w_cls, float w_site, float *loss_out, float *dWcls, float *dbcls,
+                       float *dWsite, float *dbsite, float beta, int B, int L, int C, hipStream_t st);
 struct WgradDeferred;
 int launch_wgrad(const float *dY, const float *dy_amax, const float *X, const float *x_amax, float *dW, float *db, int64_t M,
                  int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what, int x_mode = TOAD_X_F32,

@@ -96,9 +96,20 @@ template <int T, int DQ /* = D/(4*LPR) float4 per lane */, int LQ /* = L/(4*LPR)
 __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
     const float *__restrict__ Pa, const float *__restrict__ Pb, int64_t ldp, const float *__restrict__ H,
     const float *__restrict__ Wc, const float *__restrict__ bc, float *__restrict__ A_raw,
-    float *__restrict__ partials, int N, DropArgs drop_a, DropArgs drop_b, int Dr, int Lr, int Tr) {
+    float *__restrict__ partials, int N, DropArgs drop_a, DropArgs drop_b, int Dr, int Lr, int Tr, const int64_t *__restrict__ seg) {
     constexpr int D = DQ * 4 * LPR, L = LQ * 4 * LPR;
     const int D_ = GEN ? Dr : D, L_ = GEN ? Lr : L, T_ = GEN ? Tr : T;      // run-time shape (== the template's unless GEN)
+    // Batched launch (seg != NULL; the ragged multi-slide step): blockIdx.y = slide, whose rows [seg[y], seg[y+1]) of the shared
+    // activations are pooled on their own; every (slide, block) writes its own partial record, workgroups beyond a short slide's
+    // rows write an empty one (max = -inf), which the merge ignores.
+    if (seg) {
+        const int64_t r0 = seg[blockIdx.y];
+        N = (int)(seg[blockIdx.y + 1] - r0);
+        Pa += r0 * ldp; Pb += r0 * ldp; A_raw += r0 * T_;
+        if (POOL) H += r0 * L_;
+        drop_a.seed += (uint64_t)blockIdx.y * 0x9E3779B97F4A7C15ull; drop_b.seed += (uint64_t)blockIdx.y * 0x9E3779B97F4A7C15ull;
+    }
+    const int pblk = blockIdx.y * gridDim.x + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane / LPR, c = lane % LPR;     // LPR-lane group = one row; c = float4 slot
     const bool dropping = drop_a.thresh != 0;       // train-mode Dropout(0.25) after tanh and after sigmoid
@@ -256,7 +267,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
     } else {
         __syncthreads();
     }
-    float *out = partials + (int64_t)blockIdx.x * pool_partial_floats(L_, T_);
+    float *out = partials + (int64_t)pblk * pool_partial_floats(L_, T_);
     for (int e = tid; e < T_ * L_ / 4; e += POOL_THREADS) {
         const int t = e / (L_ / 4), q = e % (L_ / 4);
         f32x4 v = ld4(&sm_acc[0][t][q * 4]);
@@ -290,7 +301,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 __global__ __launch_bounds__(256) void gated_pool_combine_kernel(const float *__restrict__ partials, int G, int L,
                                                                   int T, float *__restrict__ M,
-                                                                  float *__restrict__ stats) {
+                                                                  float *__restrict__ stats, int m_stride, int s_stride) {
+    // blockIdx.y = slide of a batched launch (0 otherwise): its G partial records, its M / stats record
+    partials += (int64_t)blockIdx.y * G * pool_partial_floats(L, T);
+    M += (int64_t)blockIdx.y * m_stride; stats += (int64_t)blockIdx.y * s_stride;
     __shared__ float red[2][4];
     __shared__ float wgt[512];                       // exp(m_b - m) of the first 512 partials (the launch grid of the forward is capped there)
     __shared__ __attribute__((aligned(16))) float sacc[4][32];
@@ -366,9 +380,20 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
     const float *__restrict__ Wc, const float *__restrict__ A_raw, const float *__restrict__ stats,
     const float *__restrict__ Mp, const float *__restrict__ dM, const float *__restrict__ dA_ext,
     float *__restrict__ dPa, float *__restrict__ dPb, int64_t ldd, float *__restrict__ dH,
-    float *__restrict__ partials, float *__restrict__ dp_amax, int N, DropArgs drop_a, DropArgs drop_b, int Dr, int Lr, int Tr) {
+    float *__restrict__ partials, float *__restrict__ dp_amax, int N, DropArgs drop_a, DropArgs drop_b, int Dr, int Lr, int Tr,
+    const int64_t *__restrict__ seg, int m_stride, int s_stride) {
     constexpr int D = DQ * 4 * LPR, L = LQ * 4 * LPR;
     const int D_ = GEN ? Dr : D, L_ = GEN ? Lr : L, T_ = GEN ? Tr : T;
+    if (seg) {          // batched launch: blockIdx.y = slide (see gated_pool_fwd_kernel); its softmax statistics, M and dM records
+        const int64_t r0 = seg[blockIdx.y];
+        N = (int)(seg[blockIdx.y + 1] - r0);
+        Pa += r0 * ldp; Pb += r0 * ldp; H += r0 * L_; A_raw += r0 * T_; dPa += r0 * ldd; dPb += r0 * ldd;
+        if (dH) dH += r0 * L_;
+        if (dA_ext) dA_ext += r0 * T_;
+        stats += (int64_t)blockIdx.y * s_stride; Mp += (int64_t)blockIdx.y * m_stride; dM += (int64_t)blockIdx.y * m_stride;
+        drop_a.seed += (uint64_t)blockIdx.y * 0x9E3779B97F4A7C15ull; drop_b.seed += (uint64_t)blockIdx.y * 0x9E3779B97F4A7C15ull;
+    }
+    const int pblk = blockIdx.y * gridDim.x + blockIdx.x;
     const bool dropping = drop_a.thresh != 0;
     __shared__ __attribute__((aligned(16))) float s_dm[T][L];
     __shared__ __attribute__((aligned(16))) float s_wc[T][D];
@@ -535,7 +560,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
         }
     }
     __syncthreads();
-    float *out = partials + (int64_t)blockIdx.x * bwd_partial_floats(D_, T_);
+    float *out = partials + (int64_t)pblk * bwd_partial_floats(D_, T_);
     for (int e = tid; e < T_ * D_ / 4; e += POOL_THREADS) {
         const int t = e / (D_ / 4), q = e % (D_ / 4);
         f32x4 v = ld4(&s_red[0][t][q * 4]);
@@ -618,11 +643,11 @@ static bool shape_ok(int L, int D, int T) {
 template <bool POOL>
 static void launch_fwd(int L, int D, int T, int grid, hipStream_t st, const float *Pa, const float *Pb, int64_t ldp,
                        const float *H, const float *Wc, const float *bc, float *A_raw, float *partials, int N,
-                       DropArgs da, DropArgs db) {
+                       DropArgs da, DropArgs db, const int64_t *seg = nullptr, int nseg = 1) {
 #define TOAD_FWD_CASE(TT, DD, LL)                                                                             \
     if (T == TT && D == DD && L == LL) {                                                                      \
-        hipLaunchKernelGGL((gated_pool_fwd_kernel<TT, DD / (4 * LPR), LL / (4 * LPR), POOL>), dim3(grid), dim3(POOL_THREADS), 0, st, \
-                           Pa, Pb, ldp, H, Wc, bc, A_raw, partials, N, da, db, D, L, T);                      \
+        hipLaunchKernelGGL((gated_pool_fwd_kernel<TT, DD / (4 * LPR), LL / (4 * LPR), POOL>), dim3(grid, nseg), dim3(POOL_THREADS), 0, st, \
+                           Pa, Pb, ldp, H, Wc, bc, A_raw, partials, N, da, db, D, L, T, seg);                 \
         return;                                                                                               \
     }
     TOAD_FWD_CASE(2, 384, 512)
@@ -634,18 +659,19 @@ static void launch_fwd(int L, int D, int T, int grid, hipStream_t st, const floa
     TOAD_FWD_CASE(1, 384, 1024)
     TOAD_FWD_CASE(1, 256, 1024)
 #undef TOAD_FWD_CASE
-    hipLaunchKernelGGL((gated_pool_fwd_kernel<GEN_T, GEN_DQ, GEN_LQ, POOL, true>), dim3(grid), dim3(POOL_THREADS), 0, st, Pa, Pb, ldp, H, Wc, bc,
-                       A_raw, partials, N, da, db, D, L, T);
+    hipLaunchKernelGGL((gated_pool_fwd_kernel<GEN_T, GEN_DQ, GEN_LQ, POOL, true>), dim3(grid, nseg), dim3(POOL_THREADS), 0, st, Pa, Pb, ldp, H, Wc, bc,
+                       A_raw, partials, N, da, db, D, L, T, seg);
 }
 
 static void launch_bwd(int L, int D, int T, int grid, hipStream_t st, const float *Pa, const float *Pb, int64_t ldp,
                        const float *H, const float *Wc, const float *A_raw, const float *stats, const float *M,
                        const float *dM, const float *dA_ext, float *dPa, float *dPb, int64_t ldd, float *dH,
-                       float *partials, float *dp_amax, int N, DropArgs da, DropArgs db) {
+                       float *partials, float *dp_amax, int N, DropArgs da, DropArgs db, const int64_t *seg = nullptr, int nseg = 1,
+                       int m_stride = 0, int s_stride = 0) {
 #define TOAD_BWD_CASE(TT, DD, LL)                                                                             \
     if (T == TT && D == DD && L == LL) {                                                                      \
-        hipLaunchKernelGGL((gated_pool_bwd_kernel<TT, DD / (4 * LPR), LL / (4 * LPR)>), dim3(grid), dim3(POOL_THREADS), 0, st, Pa, \
-                           Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, partials, dp_amax, N, da, db, D, L, T); \
+        hipLaunchKernelGGL((gated_pool_bwd_kernel<TT, DD / (4 * LPR), LL / (4 * LPR)>), dim3(grid, nseg), dim3(POOL_THREADS), 0, st, Pa, \
+                           Pb, ldp, H, Wc, A_raw, stats, M, dM, dA_ext, dPa, dPb, ldd, dH, partials, dp_amax, N, da, db, D, L, T, seg, m_stride, s_stride); \
         return;                                                                                               \
     }
     TOAD_BWD_CASE(2, 384, 512)
@@ -657,8 +683,8 @@ static void launch_bwd(int L, int D, int T, int grid, hipStream_t st, const floa
     TOAD_BWD_CASE(1, 384, 1024)
     TOAD_BWD_CASE(1, 256, 1024)
 #undef TOAD_BWD_CASE
-    hipLaunchKernelGGL((gated_pool_bwd_kernel<GEN_T, GEN_DQ, GEN_LQ, true>), dim3(grid), dim3(POOL_THREADS), 0, st, Pa, Pb, ldp, H, Wc, A_raw, stats,
-                       M, dM, dA_ext, dPa, dPb, ldd, dH, partials, dp_amax, N, da, db, D, L, T);
+    hipLaunchKernelGGL((gated_pool_bwd_kernel<GEN_T, GEN_DQ, GEN_LQ, true>), dim3(grid, nseg), dim3(POOL_THREADS), 0, st, Pa, Pb, ldp, H, Wc, A_raw, stats,
+                       M, dM, dA_ext, dPa, dPb, ldd, dH, partials, dp_amax, N, da, db, D, L, T, seg, m_stride, s_stride);
 }
 
 }  // namespace toad
@@ -695,7 +721,49 @@ extern "C" int toad_gated_pool_fwd_f32(const float *Pa, const float *Pb, int64_t
     launch_fwd<true>(L, D, T, grid, st, Pa, Pb, ldp, H, Wc, bc, A_raw, (float *)ws, (int)N, da, db);
     int rc = check_launch(what);
     if (rc) return rc;
-    hipLaunchKernelGGL(gated_pool_combine_kernel, dim3(T * ((L + 31) / 32)), dim3(256), 0, st, (const float *)ws, grid, L, T, M, stats);
+    hipLaunchKernelGGL(gated_pool_combine_kernel, dim3(T * ((L + 31) / 32)), dim3(256), 0, st, (const float *)ws, grid, L, T, M, stats, 0, 0);
+    return check_launch(what);
+}
+
+// ---- batched (ragged multi-slide) launches: ONE launch pools every slide of a batch on its row range of the shared activations ----
+// grid = (gx, B): gx workgroups per slide, sized for the longest slide and capped so that B * gx <= 4096 partial records.
+static int batch_gx(int64_t max_n, int B) {
+    int64_t gx = (max_n + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP;
+    const int64_t cap = 4096 / B > 0 ? 4096 / B : 1;
+    if (gx > cap) gx = cap;
+    if (gx > 512) gx = 512;
+    return (int)(gx < 1 ? 1 : gx);
+}
+size_t toad::pool_batch_ws_bytes(int B, int L, int D, int T) {       // forward partials, then backward partials (either fits 4096 records)
+    const size_t f = (size_t)4096 * (size_t)pool_partial_floats(L, T) * sizeof(float), b = (size_t)4096 * (size_t)bwd_partial_floats(D, T) * sizeof(float);
+    (void)B;
+    return (f > b ? f : b) + 256;
+}
+int toad::launch_pool_fwd_batch(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *bc, float *A_raw, float *M,
+                                int m_stride, float *stats, int s_stride, void *ws, const int64_t *seg_dev, int B, int64_t max_n, int L, int D, int T,
+                                float drop_p, uint64_t seed_a, uint64_t seed_b, hipStream_t st) {
+    const char *what = "toad_gated_pool_fwd_f32 (batched)";
+    if (!shape_ok(L, D, T) || B < 1 || B > 4096) { set_error("%s: unsupported shape", what); return TOAD_ESHAPE; }
+    const DropArgs da = make_drop(drop_p, seed_a), db = make_drop(drop_p, seed_b);
+    const int gx = batch_gx(max_n, B);
+    launch_fwd<true>(L, D, T, gx, st, Pa, Pb, ldp, H, Wc, bc, A_raw, (float *)ws, 0, da, db, seg_dev, B);
+    if (int rc = check_launch(what)) return rc;
+    hipLaunchKernelGGL(gated_pool_combine_kernel, dim3(T * ((L + 31) / 32), B), dim3(256), 0, st, (const float *)ws, gx, L, T, M, stats, m_stride, s_stride);
+    return check_launch(what);
+}
+int toad::launch_pool_bwd_batch(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *A_raw, const float *stats,
+                                int s_stride, const float *M, const float *dM, int m_stride, float *dPa, float *dPb, int64_t ldd, float *dH, float *dWc,
+                                float *dbc, float beta, void *ws, const int64_t *seg_dev, int B, int64_t max_n, int L, int D, int T, float drop_p,
+                                uint64_t seed_a, uint64_t seed_b, hipStream_t st) {
+    const char *what = "toad_gated_pool_bwd_f32 (batched)";
+    if (!shape_ok(L, D, T) || B < 1 || B > 4096) { set_error("%s: unsupported shape", what); return TOAD_ESHAPE; }
+    const DropArgs da = make_drop(drop_p, seed_a), db = make_drop(drop_p, seed_b);
+    const int gx = batch_gx(max_n, B);
+    launch_bwd(L, D, T, gx, st, Pa, Pb, ldp, H, Wc, A_raw, stats, M, dM, nullptr, dPa, dPb, ldd, dH, (float *)ws, nullptr, 0, da, db, seg_dev, B, m_stride, s_stride);
+    if (int rc = check_launch(what)) return rc;
+    const int n = T * D + T, nred = (n + 3) / 4;
+    hipLaunchKernelGGL(bwd_partial_reduce_kernel, dim3(nred), dim3(256), 0, st, (const float *)ws, gx * B, bwd_partial_floats(D, T), T * D, T, dWc, dbc, beta, nred,
+                       (const float *)nullptr, 0, (float *)nullptr);
     return check_launch(what);
 }
 

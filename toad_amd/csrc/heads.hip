@@ -143,7 +143,18 @@ __global__ __launch_bounds__(1024) void heads_ce_fused_kernel(
     const float *__restrict__ Wsite, const float *__restrict__ bsite, const int64_t *__restrict__ label,
     const int64_t *__restrict__ site, float w_cls, float w_site, float *Mcat, float *logits, float *Y_prob, int64_t *Y_hat,
     float *site_logits, float *site_prob, int64_t *site_hat, float *loss_out, float *dlogits, float *dsite, float *dWcls,
-    float *dbcls, float *dWsite, float *dbsite, float *dM, float beta, int L, int C, int cache_w) {
+    float *dbcls, float *dWsite, float *dbsite, float *dM, float beta, int L, int C, int cache_w, int64_t rec) {
+    // rec != 0: batched launch (the ragged multi-slide step): blockIdx.x = slide b; every per-slide pointer moves by b * rec BYTES (sex /
+    // label / site by b elements, loss_out by 3 b), dlogits / dsite are exported per slide, and the head-weight gradients - a sum over
+    // the batch - are formed afterwards by heads_wgrad_batch_kernel (dWcls == NULL here)
+    if (rec) {
+        const int64_t b = blockIdx.x, o = b * rec;
+#define TOAD_MV(p) p = reinterpret_cast<decltype(p)>(reinterpret_cast<uintptr_t>(p) + (uintptr_t)o)
+        TOAD_MV(M); TOAD_MV(Mcat); TOAD_MV(logits); TOAD_MV(Y_prob); TOAD_MV(Y_hat); TOAD_MV(site_logits); TOAD_MV(site_prob); TOAD_MV(site_hat);
+        TOAD_MV(dM); TOAD_MV(dlogits); TOAD_MV(dsite);
+#undef TOAD_MV
+        sex += b; label += b; site += b; loss_out += 3 * b;
+    }
     extern __shared__ float s_all[];                 // [2][L+1] Mcat | [C] logits | [2] site logits | [C] dlogits | [2] dsite | cache_w: [C+2][L+1] weights
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int LP = L + 1;
@@ -190,6 +201,7 @@ __global__ __launch_bounds__(1024) void heads_ce_fused_kernel(
     const int total = (C + 3) * LP;
     for (int e = tid; e < total; e += 1024) {
         const int r = e / LP, k = e % LP;
+        if (r < C + 2 && !dWcls) continue;              // batched: weight gradients are summed over the slides by heads_wgrad_batch_kernel
         if (r < C) {
             const int64_t o = (int64_t)r * LP + k;
             dWcls[o] = (beta != 0.f ? beta * dWcls[o] : 0.f) + s_dl[r] * s_m[k];
@@ -211,6 +223,30 @@ __global__ __launch_bounds__(1024) void heads_ce_fused_kernel(
             dM[L + k] = d1;
         }
     }
+}
+
+// Head-weight gradients of a batch: dWcls[c, :] = beta dWcls[c, :] + sum_b dlogits_b[c] Mcat_b[0, :], dWsite[s, :] likewise with Mcat_b[1, :],
+// biases = sums of dlogits / dsite. One thread per output element, slides summed in index order (deterministic); the inputs are a few
+// hundred KB and stay in L2.
+__global__ __launch_bounds__(256) void heads_wgrad_batch_kernel(const float *__restrict__ dl, const float *__restrict__ ds, const float *__restrict__ Mcat,
+                                                                 int64_t rec, float *dWcls, float *dbcls, float *dWsite, float *dbsite, float beta, int B,
+                                                                 int L, int C) {
+    const int LP = L + 1;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= (C + 2) * LP) return;
+    const int r = e / LP, k = e % LP;
+    const bool cls = r < C;
+    const int c = cls ? r : r - C;
+    const char *g = reinterpret_cast<const char *>(cls ? dl : ds), *m = reinterpret_cast<const char *>(Mcat);
+    float acc = 0.f, bacc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float gv = reinterpret_cast<const float *>(g + (int64_t)b * rec)[c];
+        acc = fmaf(gv, reinterpret_cast<const float *>(m + (int64_t)b * rec)[(cls ? 0 : LP) + k], acc);
+        bacc += gv;
+    }
+    float *dw = cls ? dWcls + (int64_t)c * LP + k : dWsite + (int64_t)c * LP + k;
+    *dw = (beta != 0.f ? beta * *dw : 0.f) + acc;
+    if (k == 0) { float *db = cls ? dbcls + c : dbsite + c; *db = (beta != 0.f ? beta * *db : 0.f) + bacc; }
 }
 
 // Adam over one flat buffer, same update as torch.optim.Adam (L2 weight decay folded into the gradient;
@@ -300,7 +336,26 @@ extern "C" int toad_heads_ce_fused_f32(const float *M, const float *sex, const f
     if (cache_w) smem += wbytes;
     hipLaunchKernelGGL(heads_ce_fused_kernel, dim3(1), dim3(1024), smem, (hipStream_t)stream, M, sex, Wcls, bcls, Wsite, bsite, label,
                        site, w_cls, w_site, Mcat, logits, Y_prob, Y_hat, site_logits, site_prob, site_hat, loss_out, dlogits, dsite,
-                       dWcls, dbcls, dWsite, dbsite, dM, beta, L, C, cache_w);
+                       dWcls, dbcls, dWsite, dbsite, dM, beta, L, C, cache_w, (int64_t)0);
+    return check_launch(what);
+}
+
+int toad::launch_heads_batch(const HeadsBatch &hb, const float *sex, const float *Wcls, const float *bcls, const float *Wsite, const float *bsite,
+                             const int64_t *label, const int64_t *site, float w_cls, float w_site, float *loss_out, float *dWcls, float *dbcls,
+                             float *dWsite, float *dbsite, float beta, int B, int L, int C, hipStream_t st) {
+    const char *what = "toad_heads_ce_fused_f32 (batched)";
+    if (L <= 0 || L > 8192 || C <= 0 || C > 1024 || C > L || B < 1) { set_error("%s: unsupported L=%d C=%d B=%d", what, L, C, B); return TOAD_ESHAPE; }
+    if ((size_t)2 * (L + 1) * sizeof(float) > hb.rec || (size_t)C * sizeof(float) > hb.rec) { set_error("%s: per-slide record too small", what); return TOAD_EWORKSPACE; }
+    size_t smem = (size_t)(2 * (L + 1) + 2 * C + 4) * sizeof(float);
+    const size_t wbytes = (size_t)(C + 2) * (L + 1) * sizeof(float);
+    const int cache_w = smem + wbytes <= 60 * 1024 ? 1 : 0;
+    if (cache_w) smem += wbytes;
+    hipLaunchKernelGGL(heads_ce_fused_kernel, dim3(B), dim3(1024), smem, st, hb.M, sex, Wcls, bcls, Wsite, bsite, label, site, w_cls, w_site, hb.Mcat,
+                       hb.logits, hb.yprob, hb.yhat, hb.slog, hb.sprob, hb.shat, loss_out, hb.dl, hb.ds, (float *)nullptr, (float *)nullptr,
+                       (float *)nullptr, (float *)nullptr, hb.dM, beta, L, C, cache_w, (int64_t)hb.rec);
+    if (int rc = check_launch(what)) return rc;
+    hipLaunchKernelGGL(heads_wgrad_batch_kernel, dim3(((C + 2) * (L + 1) + 255) / 256), dim3(256), 0, st, (const float *)hb.dl, (const float *)hb.ds,
+                       (const float *)hb.Mcat, (int64_t)hb.rec, dWcls, dbcls, dWsite, dbsite, beta, B, L, C);
     return check_launch(what);
 }
 

@@ -464,7 +464,7 @@ extern "C" int toad_mil_step_xp_f32(const float *const *params, float *const *gr
 // the CONCATENATION, and the pooling gradient dH_pool is materialised (per-slide softmax statistics cannot ride in one GEMM
 // epilogue) instead of being recomputed in the dgrad. Train-mode dropout masks hash the element index in the concatenation.
 namespace toad {
-struct MultiSmall { float *stats, *M, *Mcat, *logits, *yprob, *slog, *sprob, *dM; int64_t *yhat, *shat; size_t total; };
+struct MultiSmall { float *stats, *M, *Mcat, *logits, *yprob, *slog, *sprob, *dM, *dl, *dsv; int64_t *yhat, *shat, *seg; void *pool_ws; size_t total; };
 constexpr size_t kSlideRec = 8192;                  // bytes reserved per slide and per small array (>= T*(L+1)*4 = 4104, 256-B multiple)
 static MultiSmall multi_small_layout(int B, char *base) {
     MultiSmall m{};
@@ -475,6 +475,9 @@ static MultiSmall multi_small_layout(int B, char *base) {
     m.logits = (float *)P(c.take(n, 256)); m.yprob = (float *)P(c.take(n, 256)); m.slog = (float *)P(c.take(n, 256));
     m.sprob = (float *)P(c.take(n, 256)); m.dM = (float *)P(c.take(n, 256));
     m.yhat = (int64_t *)P(c.take(n, 256)); m.shat = (int64_t *)P(c.take(n, 256));
+    m.dl = (float *)P(c.take(n, 256)); m.dsv = (float *)P(c.take(n, 256));
+    m.seg = (int64_t *)P(c.take((size_t)(B + 1) * sizeof(int64_t), 256));
+    m.pool_ws = P(c.take(pool_batch_ws_bytes(B, kL, 384, kT), 4096));
     m.total = up(c.off, 256);
     return m;
 }
@@ -514,12 +517,9 @@ extern "C" int toad_mil_multi_step_f32(const float *const *params, float *const 
     hipStream_t st = (hipStream_t)stream;
     const int D2 = 2 * D;
     const DropSeeds ds = drop_seeds(drop_p, seed);
-    const uint64_t G = 0x9E3779B97F4A7C15ull;
     const EpiScalars relu1{1, 1.f, make_drop(drop_p, ds.s1)}, relu2{1, 1.f, make_drop(drop_p, ds.s2)}, lin{0, 1.f, make_drop(0.f, 0)};
     const EpiScalars msk{0, ds.mscale, make_drop(0.f, 0)};
     const H2Pool nopool{nullptr, nullptr, nullptr, 0};
-    auto rec = [&](void *base, int b) { return reinterpret_cast<char *>(base) + (size_t)b * kSlideRec; };
-
     // ---- forward: one launch splits the five weight operands and zeroes both groups of abs-max arrays; three GEMMs over all rows
     {
         const H2Operand ops5[5] = {{p.w1, kL0, 1, kL, kL0, w.planes[W_1], w.binv[W_1]}, {p.w2, kL, 1, kL, kL, w.planes[W_2], w.binv[W_2]},
@@ -533,27 +533,23 @@ extern "C" int toad_mil_multi_step_f32(const float *const *params, float *const 
     TOAD_TRY(launch_nt_h2(Xcat, kL0, f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h1, f.bits_h1, st, what));
     TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h, nullptr, st, what));
     TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nullptr, nopool, w.slabs, nullptr, nullptr, st, what));
-    // ---- per slide: fused pool forward on its row range, then heads + weighted CE + heads backward (one single-workgroup launch)
-    for (int b = 0; b < B; ++b) {
-        const int64_t r0 = offsets[b], nb = offsets[b + 1] - r0;
-        float *stats_b = (float *)rec(ms.stats, b), *M_b = (float *)rec(ms.M, b);
-        TOAD_TRY(toad_gated_pool_fwd_f32(f.P + r0 * D2, f.P + r0 * D2 + D, D2, f.H + r0 * kL, p.wc, p.bc, f.A_raw + r0 * kT, M_b, stats_b, w.pool_ws,
-                                         w.pool_ws_bytes, nb, kL, D, kT, drop_p, ds.sa + (uint64_t)b * G, ds.sb + (uint64_t)b * G, st));
-        const float bb = b == 0 ? beta : 1.f;
-        TOAD_TRY(toad_heads_ce_fused_f32(M_b, sex + b, p.wcls, p.bcls, p.wsite, p.bsite, label + b, site + b, w_cls, w_site, (float *)rec(ms.Mcat, b),
-                                         (float *)rec(ms.logits, b), (float *)rec(ms.yprob, b), (int64_t *)rec(ms.yhat, b), (float *)rec(ms.slog, b),
-                                         (float *)rec(ms.sprob, b), (int64_t *)rec(ms.shat, b), loss_out + 3 * b, nullptr, nullptr, grads[8], grads[9],
-                                         grads[10], grads[11], (float *)rec(ms.dM, b), bb, kL, C, st));
-        if (logits_out) (void)hipMemcpyAsync(logits_out + (size_t)b * C, rec(ms.logits, b), C * sizeof(float), hipMemcpyDeviceToDevice, st);
-        if (site_logits_out) (void)hipMemcpyAsync(site_logits_out + (size_t)b * 2, rec(ms.slog, b), 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
-    }
-    // ---- per slide: pooling backward -> dP rows, the pooling gradient dH_pool rows (into the dZ2 buffer), dWc / dbc accumulated
-    for (int b = 0; b < B; ++b) {
-        const int64_t r0 = offsets[b], nb = offsets[b + 1] - r0;
-        TOAD_TRY(launch_pool_bwd(f.P + r0 * D2, f.P + r0 * D2 + D, D2, f.H + r0 * kL, p.wc, f.A_raw + r0 * kT, (float *)rec(ms.stats, b), (float *)rec(ms.M, b),
-                                 (float *)rec(ms.dM, b), nullptr, w.dP + r0 * D2, w.dP + r0 * D2 + D, D2, w.dZ2 + r0 * kL, grads[6], grads[7], b == 0 ? beta : 1.f,
-                                 nullptr, false, w.poolb_ws, w.poolb_ws_bytes, nb, kL, D, kT, drop_p, ds.sa + (uint64_t)b * G, ds.sb + (uint64_t)b * G, st));
-    }
+    // ---- all slides at once (blockIdx.y = slide): fused pool forward on each row range + merge; heads + weighted CE + heads backward with
+    // one workgroup per slide, then the head-weight gradients summed over the batch; pooling backward (dP rows, the pooling gradient
+    // dH_pool rows into the dZ2 buffer, dWc / dbc summed over the batch). Five launches + two small copies, whatever B is - a 64-slide
+    // batch of 256-patch bags was 320 launches of mostly idle kernels when this ran slide by slide.
+    int64_t max_n = 0;
+    for (int b = 0; b < B; ++b) if (offsets[b + 1] - offsets[b] > max_n) max_n = offsets[b + 1] - offsets[b];
+    (void)hipMemcpyAsync(ms.seg, offsets, (size_t)(B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st);      // pageable source: staged before the call returns
+    const int rec_f = (int)(kSlideRec / sizeof(float));
+    TOAD_TRY(launch_pool_fwd_batch(f.P, f.P + D, D2, f.H, p.wc, p.bc, f.A_raw, ms.M, rec_f, ms.stats, rec_f, ms.pool_ws, ms.seg, B, max_n, kL, D, kT, drop_p,
+                                   ds.sa, ds.sb, st));
+    const HeadsBatch hb{ms.M, ms.Mcat, ms.logits, ms.yprob, ms.yhat, ms.slog, ms.sprob, ms.shat, ms.dM, ms.dl, ms.dsv, kSlideRec};
+    TOAD_TRY(launch_heads_batch(hb, sex, p.wcls, p.bcls, p.wsite, p.bsite, label, site, w_cls, w_site, loss_out, grads[8], grads[9], grads[10], grads[11], beta,
+                                B, kL, C, st));
+    if (logits_out) (void)hipMemcpy2DAsync(logits_out, (size_t)C * sizeof(float), ms.logits, kSlideRec, (size_t)C * sizeof(float), B, hipMemcpyDeviceToDevice, st);
+    if (site_logits_out) (void)hipMemcpy2DAsync(site_logits_out, 2 * sizeof(float), ms.slog, kSlideRec, 2 * sizeof(float), B, hipMemcpyDeviceToDevice, st);
+    TOAD_TRY(launch_pool_bwd_batch(f.P, f.P + D, D2, f.H, p.wc, f.A_raw, ms.stats, rec_f, ms.M, ms.dM, rec_f, w.dP, w.dP + D, D2, w.dZ2, grads[6], grads[7], beta,
+                                   ms.pool_ws, ms.seg, B, max_n, kL, D, kT, drop_p, ds.sa, ds.sb, st));
     // the slides' row ranges do not line up with the 256-row blocks of the concatenation: dP's abs-max array is measured in one pass
     TOAD_TRY(launch_absmax(w.dP, D2, N, D2, w.amax_dP, false, st, what));
     // ---- backward GEMMs over all rows
