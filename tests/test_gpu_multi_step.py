@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import toad_oracle as orc
-from tests.helpers import SLOT2KEY, assert_grad_close, grad_scale
+from tests.helpers import SLOT2KEY, assert_grad_close, assert_grad_close_or_few_flips, grad_scale
 
 pytestmark = pytest.mark.gpu
 
@@ -77,9 +77,11 @@ def test_batch_gradient_is_the_sum_of_the_slide_gradients(cuda, lens):
     for slot, key in SLOT2KEY.items():
         dev = (tot32[key].double() - tot64[key]).abs().max().item()
         sc = grad_scale(tot64, key)
-        assert_grad_close(got2[slot], tot64[key], 2e-5, sc, what=f"batch vs oracle: {key}", floor=10.0 * dev)
+        # (`dev` only knows the oracle's own flips; the device can flip where the CPU did not: trunk gradients go through the rank-one test)
+        chk = assert_grad_close_or_few_flips if slot in ("w1", "b1", "w2", "b2") else assert_grad_close
+        chk(got2[slot], tot64[key], 2e-5, sc, what=f"batch vs oracle: {key}", floor=10.0 * dev)
         # and the batch call against B one-slide calls of the same kernels
-        assert_grad_close(got2[slot], got1[slot], 5e-5, sc, what=f"batch vs per-slide: {key}", floor=20.0 * dev)
+        chk(got2[slot], got1[slot], 5e-5, sc, what=f"batch vs per-slide: {key}", floor=20.0 * dev)
     # beta = 1 accumulates on top
     g3 = {k: g2[k].clone() for k in ops.STEP_SLOTS}
     ops.mil_multi_step(w, g3, 1.0, [s[0] for s in dev_slides], sex, label, site, 0.75 / B, 0.25 / B)
