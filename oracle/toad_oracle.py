@@ -8,7 +8,7 @@ It is never imported by the product package and never runs on the GPU.
 Parity status: PINNED.  ``oracle/pin_against_reference.py`` imports the unmodified
 reference model in the build container, checks this restatement against it
 (forward dict, all 14 parameter gradients, ``attention_only``/``return_features``
-for N in {1,2,63,64,65,256,777,10000}) and writes the golden vectors committed under
+for N in {0,1,2,63,64,65,256,777,1024 (x30, saturated softmax),300 (all rows equal),10000,100000}, C in {2,18}) and writes the golden vectors committed under
 ``tests/golden/``.  The reference has no tests or golden vectors of its own
 (SURVEY.md §4), so the imported reference is the pin.
 

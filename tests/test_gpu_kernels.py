@@ -1,6 +1,6 @@
 """GPU: each C-ABI kernel against its CPU twin in the oracle on the same seeded inputs.
-Tolerances: fp32 GEMMs 1e-5 of the output scale (exact-fp32 MFMA differs from MKL only by
-summation order); fused pool 1e-5 abs (v_exp/v_rcp based tanh/sigmoid, abs err ~1e-7/elem)."""
+Tolerances: fp32-equivalent GEMMs 1e-5 of the output scale (fp16 two-piece operands, three MFMA terms, fp32 accumulation: as close to
+the exact value as an fp32 fma chain, differing from MKL by summation order and round-off); fused pool 1e-5 abs (v_exp/v_rcp based tanh/sigmoid, abs err ~1e-7/elem)."""
 import pytest
 import torch
 
