@@ -130,3 +130,23 @@ def test_train_mode_dropout_runs_and_is_seeded(cuda):
         res.append((loss.clone(), g["w1"].clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert not torch.equal(res[0][1], res[2][1]) and torch.isfinite(res[2][1]).all()
+
+
+def test_train_loop_dp_learns_on_small_bags(cuda):
+    """train_loop_dp: one optimiser step per batch of slides through the ragged multi-slide call; the class loss falls on a learnable signal
+    and the epoch statistics equal the mean of the per-slide losses the step reports."""
+    from toad_amd.dp import SlideShardedDP
+    from toad_amd.train import train_loop_dp
+    model, _ = _model(cuda, seed=21)
+    model.train()
+    dp = SlideShardedDP(model, {"lr": 5e-4, "weight_decay": 1e-5})
+    slides = []
+    for i in range(48):
+        g = torch.Generator().manual_seed(400 + i)
+        x = torch.randn(96 + (i * 31) % 200, 1024, generator=g)
+        x[:, :16] += (i % 3) * 1.0
+        slides.append((x, torch.tensor([i % 3]), torch.tensor([i % 2]), torch.tensor([float(i % 2)])))
+    first = train_loop_dp(0, dp, slides, batch_slides=16)
+    for e in range(1, 6):
+        last = train_loop_dp(e, dp, slides, batch_slides=16)
+    assert first["slides"] == 48 and last["cls_loss"] < 0.8 * first["cls_loss"], (first, last)

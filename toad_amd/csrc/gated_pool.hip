@@ -62,15 +62,19 @@ __device__ __forceinline__ f32x4 ld4s(const float *p) {
 
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
 
-// a = tanh(x), b = sigmoid(y) from two v_exp_f32 and two v_rcp_f32.
+// a = tanh(x), b = sigmoid(y) from two v_exp_f32 and one v_rcp_f32.
 //   u = e^{2x} (x clamped to +-20: tanh saturates to 1-4e-18, u stays finite), v = e^{-y}
 //   a = (u-1)/(u+1), b = 1/(1+v).  Absolute error ~1e-7 (fp32 eps) everywhere.
+// (round 3: ONE reciprocal for both - r = 1 / ((u+1)(1+v)), a = (u-1)(1+v) r, b = (u+1) r - the backward kernel is co-limited by its
+//  transcendental rate, and this is a quarter of them. y is clamped at -40 so that (u+1)(1+v) <= e^80 stays finite: sigmoid(-40) = 4e-18.)
 __device__ __forceinline__ void gate_ab(float x, float y, float &a, float &b) {
     x = __builtin_fminf(__builtin_fmaxf(x, -20.f), 20.f);
+    y = __builtin_fmaxf(y, -40.f);
     const float u = __builtin_amdgcn_exp2f(x * (2.f * kLog2e));
-    const float v = __builtin_amdgcn_exp2f(y * (-kLog2e));
-    a = (u - 1.f) * __builtin_amdgcn_rcpf(u + 1.f);
-    b = __builtin_amdgcn_rcpf(1.f + v);
+    const float v1 = 1.f + __builtin_amdgcn_exp2f(y * (-kLog2e));
+    const float r = __builtin_amdgcn_rcpf((u + 1.f) * v1);
+    a = ((u - 1.f) * v1) * r;
+    b = (u + 1.f) * r;
 }
 // g = a*b with a single reciprocal: (u-1) / ((u+1)(1+v))
 __device__ __forceinline__ float gate_g(float x, float y) {

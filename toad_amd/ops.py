@@ -411,6 +411,11 @@ class PreparedBag:
         return self
 
     def to(self, *args, **kwargs):           # already resident in its final form (train._to_device calls data.to(device))
+        dev = kwargs.get("device", args[0] if args and isinstance(args[0], (str, torch.device)) else None)
+        if dev is not None and torch.device(dev).type == "cuda" and torch.device(dev).index not in (None, self.planes.device.index):
+            raise RuntimeError(f"PreparedBag lives on {self.planes.device}; prepare it on the device that trains on it")
+        if dev is not None and torch.device(dev).type != "cuda":
+            raise RuntimeError("PreparedBag is a device-side format (toad_amd has no CPU path)")
         return self
 
     def nbytes(self) -> int:
