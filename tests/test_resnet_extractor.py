@@ -165,13 +165,11 @@ def test_implicit_conv_matches_fp64(cuda, b, h, w, cin, cout, k, s, p, res):
     ref = ref.clamp_min(0)
     assert y.shape == ref.shape
     assert (y.double() - ref).abs().max().item() <= 2e-5
-    # the implicit gather and the explicit im2col + GEMM are the same arithmetic in the same order
+    # the implicit gather and the explicit im2col + GEMM are the same products summed in another order (the streamed kernel walks
+    # the taps inside each 32-channel chunk, gemm_stream.inc; wide layers' explicit path runs on the 256x256 kernel): roundoff apart
     cols = ops.im2col_nhwc(x.to(cuda), k, k, s, p)
     y2 = ops.linear_act_res_fwd(cols, wf.to(cuda), bias.to(cuda), None if r is None else r.to(cuda).view(-1, cout), 1).cpu()
-    if cout <= 128:
-        assert torch.equal(y.view(-1, cout), y2)
-    else:       # wider layers: the explicit path runs on the 256x256 kernel (other tile shape, K-split) - same values to roundoff
-        assert (y.view(-1, cout) - y2).abs().max().item() <= 2e-5
+    assert (y.view(-1, cout) - y2).abs().max().item() <= 2e-5
 
 
 @pytest.mark.gpu

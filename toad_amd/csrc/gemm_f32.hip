@@ -53,6 +53,7 @@ __device__ __forceinline__ bool map_tile(int tiles_m, int tiles_n, int &tm, int 
 #include "gemm_h2.inc"
 #include "gemm_pt.inc"
 #include "gemm_narrow.inc"
+#include "gemm_stream.inc"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -63,7 +64,7 @@ __device__ __forceinline__ bool map_tile(int tiles_m, int tiles_n, int &tm, int 
 // additionally compiles round 1's exact-fp32 / split-bf16 arms of the MIL GEMMs and lets TOAD_GEMM_* / TOAD_EXTRACT_H2 /
 // TOAD_NARROW_RES_KMAX choose them, for A/B measurements. std::call_once makes the first call from any thread complete the
 // attribute calls before any launch (PyTorch runs backward on its own thread; the ingest workers are threads too).
-struct GemmCfg { int narrow, narrow_res_kmax, h2, big, split, ext_h2; };
+struct GemmCfg { int narrow, narrow_res_kmax, h2, big, split, ext_h2, stream; };
 #ifdef TOAD_AB_KNOBS
 static int ab_knob(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 #else
@@ -81,6 +82,7 @@ static const GemmCfg &cfg() {
         g_cfg.big = ab_knob("TOAD_GEMM_BIG", 1);
         g_cfg.split = ab_knob("TOAD_GEMM_SPLIT", 1);
         g_cfg.ext_h2 = ab_knob("TOAD_EXTRACT_H2", 1);
+        g_cfg.stream = ab_knob("TOAD_NARROW_STREAM", 1);
 #define TOAD_ATTR(K, BYTES) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES)
 #define TOAD_H2_ATTR(P, A_, M_) TOAD_ATTR((gemm_nt_h2_big_kernel<P, A_, M_, 0>), H2_SMEM)
         TOAD_H2_ATTR(false, false, 0); TOAD_H2_ATTR(false, false, 1); TOAD_H2_ATTR(false, false, 2);
@@ -99,6 +101,11 @@ static const GemmCfg &cfg() {
         TOAD_ATTR((gemm_nt_h2_narrow_kernel<2, 2, GATHER_CONV>), (NarrowCfgH2<2, 2>::SMEM));
         TOAD_ATTR((gemm_nt_h2_narrow_kernel<1, 4, GATHER_CONV>), (NarrowCfgH2<1, 4>::SMEM));
         TOAD_ATTR((gemm_nt_h2_narrow_kernel<2, 2, GATHER_STEM>), (NarrowCfgH2<2, 2>::SMEM));
+        TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 2, GATHER_NONE>), (StreamCfg<2, 2>::SMEM));
+        TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 4, GATHER_NONE>), (StreamCfg<2, 4>::SMEM));
+        TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 2, GATHER_CONV>), (StreamCfg<2, 2>::SMEM));
+        TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 4, GATHER_CONV>), (StreamCfg<2, 4>::SMEM));
+        TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 2, GATHER_STEM>), (StreamCfg<2, 2>::SMEM));
 #ifdef TOAD_AB_KNOBS
         TOAD_ATTR((gemm_nt_split_narrow_kernel<2, 2, GATHER_NONE>), (NarrowCfg<2, 2>::SMEM));
         TOAD_ATTR((gemm_nt_split_narrow_kernel<1, 4, GATHER_NONE>), (NarrowCfg<1, 4>::SMEM));
@@ -168,8 +175,20 @@ static int launch_narrow_t(const float *A, int64_t lda, const float *a_gmax, con
     const int tiles_m = (int)((M + Cfg::TM - 1) / Cfg::TM), tiles_n = (int)((N + Cfg::TN - 1) / Cfg::TN);
     unsigned short *planes = reinterpret_cast<unsigned short *>(w);
     float *binv = reinterpret_cast<float *>(w + (size_t)tiles_n * Cfg::TN * (size_t)K * 4);
-    hipLaunchKernelGGL(split_planes_narrow_h2_kernel<NB>, dim3((tiles_n * Cfg::TN + 3) / 4), dim3(256), 0, st, W, ldw, planes, binv, (int)N, (int)K, tiles_n);
+    // the streamed kernel walks an implicit convolution's k-stages channel-chunk outer, tap inner (gemm_stream.inc): its planes are split in that order
+    const bool stream = cfg().stream && K % (2 * BK) == 0;
+    const int taps = (stream && MODE == GATHER_CONV) ? (int)(K / cg.C) : 1;
+    hipLaunchKernelGGL(split_planes_narrow_h2_kernel<NB>, dim3((tiles_n * Cfg::TN + 3) / 4), dim3(256), 0, st, W, ldw, planes, binv, (int)N, (int)K, tiles_n,
+                       taps, cg.C);
     if (int rc = check_launch(what)) return rc;
+    if (stream) {                        // A streamed through registers (gemm_stream.inc): wave tile 64 x 64 / 64 x 128 instead of 32 x 64 / 32 x 128
+        constexpr int SRA = 2;
+        using SCfg = StreamCfg<SRA, NB>;
+        const int stiles_m = (int)((M + SCfg::TM - 1) / SCfg::TM);
+        hipLaunchKernelGGL((gemm_nt_h2_stream_kernel<SRA, NB, MODE>), dim3(SCfg::WG_PER_CU * PB_GRID), dim3(SCfg::THREADS), SCfg::SMEM, st, A, lda, a_gmax, planes, binv,
+                           C, ldc, (int)M, (int)N, (int)K, bias, relu, addend, cg, y_gmax, stiles_m, tiles_n);
+        return check_launch(what);
+    }
     hipLaunchKernelGGL((gemm_nt_h2_narrow_kernel<RA, NB, MODE>), dim3(PB_GRID), dim3(512), Cfg::SMEM, st, A, lda, a_gmax, planes, binv, C, ldc,
                        (int)M, (int)N, (int)K, bias, relu, addend, cg, y_gmax, tiles_m, tiles_n);
     return check_launch(what);
