@@ -64,7 +64,7 @@ __device__ __forceinline__ bool map_tile(int tiles_m, int tiles_n, int &tm, int 
 // additionally compiles round 1's exact-fp32 / split-bf16 arms of the MIL GEMMs and lets TOAD_GEMM_* / TOAD_EXTRACT_H2 /
 // TOAD_NARROW_RES_KMAX choose them, for A/B measurements. std::call_once makes the first call from any thread complete the
 // attribute calls before any launch (PyTorch runs backward on its own thread; the ingest workers are threads too).
-struct GemmCfg { int narrow, narrow_res_kmax, h2, big, split, ext_h2, stream; };
+struct GemmCfg { int narrow, narrow_res_kmax, h2, big, split, ext_h2, stream, halo; };
 #ifdef TOAD_AB_KNOBS
 static int ab_knob(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 #else
@@ -83,6 +83,7 @@ static const GemmCfg &cfg() {
         g_cfg.split = ab_knob("TOAD_GEMM_SPLIT", 1);
         g_cfg.ext_h2 = ab_knob("TOAD_EXTRACT_H2", 1);
         g_cfg.stream = ab_knob("TOAD_NARROW_STREAM", 1);
+        g_cfg.halo = ab_knob("TOAD_CONV_HALO", 1);
 #define TOAD_ATTR(K, BYTES) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES)
 #define TOAD_H2_ATTR(P, A_, M_) TOAD_ATTR((gemm_nt_h2_big_kernel<P, A_, M_, 0>), H2_SMEM)
         TOAD_H2_ATTR(false, false, 0); TOAD_H2_ATTR(false, false, 1); TOAD_H2_ATTR(false, false, 2);
@@ -106,6 +107,8 @@ static const GemmCfg &cfg() {
         TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 2, GATHER_CONV>), (StreamCfg<2, 2>::SMEM));
         TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 4, GATHER_CONV>), (StreamCfg<2, 4>::SMEM));
         TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 2, GATHER_STEM>), (StreamCfg<2, 2>::SMEM));
+        TOAD_ATTR(conv3x3_h2_halo_kernel<2>, 160 * 1024);
+        TOAD_ATTR(conv3x3_h2_halo_kernel<4>, 160 * 1024);
 #ifdef TOAD_AB_KNOBS
         TOAD_ATTR((gemm_nt_split_narrow_kernel<2, 2, GATHER_NONE>), (NarrowCfg<2, 2>::SMEM));
         TOAD_ATTR((gemm_nt_split_narrow_kernel<1, 4, GATHER_NONE>), (NarrowCfg<1, 4>::SMEM));
@@ -181,6 +184,18 @@ static int launch_narrow_t(const float *A, int64_t lda, const float *a_gmax, con
     hipLaunchKernelGGL(split_planes_narrow_h2_kernel<NB>, dim3((tiles_n * Cfg::TN + 3) / 4), dim3(256), 0, st, W, ldw, planes, binv, (int)N, (int)K, tiles_n,
                        taps, cg.C);
     if (int rc = check_launch(what)) return rc;
+    if (stream && MODE == GATHER_CONV && cfg().halo) {       // 3x3 / 1 / 1 with whole 256-pixel row blocks: the activation halo lives in LDS (gemm_stream.inc)
+        const int W = cg.W, H = cg.H;
+        const bool shape = cg.kw == 3 && K == 9 * (int64_t)cg.C && cg.stride == 1 && cg.pad == 1 && cg.Ho == H && cg.Wo == W && W >= 8 && W <= 128 &&
+                           (W & (W - 1)) == 0 && H % (256 / W) == 0 && cg.C % BK == 0 && M % 256 == 0;
+        if (shape) {
+            using HCfg = HaloCfg<NB>;
+            const int hb = HCfg::halo_bytes(W);
+            hipLaunchKernelGGL(conv3x3_h2_halo_kernel<NB>, dim3(2 * PB_GRID), dim3(HCfg::THREADS), HCfg::smem(W), st, A, a_gmax, planes, binv, C, ldc, (int)M, (int)N,
+                               (int)K, bias, relu, addend, cg, y_gmax, (int)(M / 256), tiles_n, hb);
+            return check_launch(what);
+        }
+    }
     if (stream) {                        // A streamed through registers (gemm_stream.inc): wave tile 64 x 64 / 64 x 128 instead of 32 x 64 / 32 x 128
         constexpr int SRA = 2;
         using SCfg = StreamCfg<SRA, NB>;

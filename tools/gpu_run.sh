@@ -42,6 +42,19 @@ for what in "$@"; do
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/xprof -o p -- python $ROOT/tools/extractor_bench.py ${arg:-512} 4 > $OUT/xprof.log 2>&1)
       python tools/summarize_rocprof.py $(find $OUT/xprof -name "*kernel_stats.csv" | head -1) "$TAG extractor, ${arg:-512} tiles per call" > $OUT/extractor_kernel_stats.md 2>&1
       head -24 $OUT/extractor_kernel_stats.md; tail -2 $OUT/xprof.log ;;
+    ctraffic)       # HBM fetch bytes of one convolution layer: ctraffic:"B H W Cin Cout k s p"
+      (cd /tmp && timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/ctraffic -o p -- python $ROOT/tools/conv_traffic.py $arg 3 > $OUT/ctraffic.log 2>&1)
+      find $OUT/ctraffic -name "*.db" -delete
+      python - <<PY
+import csv, glob, collections
+f = glob.glob("$OUT/ctraffic/**/*counter_collection.csv", recursive=True)[0]
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if r["Counter_Name"] == "FETCH_SIZE": agg[r["Kernel_Name"][:70]].append(float(r["Counter_Value"]))
+for k, v in agg.items():
+    print(f"{k:<70} n={len(v)} FETCH_SIZE {sum(v)/len(v)/1024:.1f} MB raw ({2*sum(v)/len(v)/1024:.1f} MB with the gfx950 wide-read x2)")
+PY
+      tail -2 $OUT/ctraffic.log ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
     *) echo "unknown job $what" ;;
