@@ -123,7 +123,9 @@ def test_stem_gather_maxpool_avgpool_bit_exact(cuda, b, h, w):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,k,n,res,act", [(4096, 64, 64, False, 1), (1000, 576, 64, False, 1), (777, 128, 512, True, 1),
-                                           (2048, 2304, 256, False, 1), (300, 160, 64, False, 1), (512, 256, 1024, True, 0)])
+                                           (2048, 2304, 256, False, 1), (300, 160, 64, False, 1), (512, 256, 1024, True, 0),
+                                           # streamed kernels with more tiles than workgroups (cross-tile prefetch, one weight chunk per tile), ragged M
+                                           (140001, 64, 128, True, 1), (200003, 64, 64, False, 1), (133000, 192, 100, False, 0)])
 def test_linear_act_res_matches_fp64(cuda, m, k, n, res, act):
     from toad_amd import ops
     g = torch.Generator().manual_seed(m + k + n)
@@ -148,6 +150,12 @@ def test_linear_act_res_matches_fp64(cuda, m, k, n, res, act):
     (2, 9, 9, 64, 128, 5, 2, 2, False),       # 5x5
     (2, 16, 16, 256, 256, 3, 1, 1, False),    # layer3 conv2: two 128-column tiles per row tile
     (1, 12, 12, 64, 300, 3, 1, 1, True),      # three column tiles, the last one ragged
+    (2, 32, 32, 128, 128, 3, 1, 1, False),    # layer2 conv2: halo kernel, 8 image rows per tile, four channel chunks
+    (4, 16, 16, 64, 192, 3, 1, 1, True),      # halo kernel with a residual and a ragged second column tile
+    (1, 128, 128, 64, 32, 3, 1, 1, False),    # halo kernel at its widest image (two rows per tile, one workgroup per CU), Cout below a tile
+    (3, 8, 8, 64, 64, 3, 1, 1, False),        # image shorter than a 256-pixel row block: streamed kernel
+    (2, 16, 16, 96, 64, 3, 1, 1, False),      # 27 k-stages (odd): the LDS-staged narrow kernel
+    (1, 40, 24, 64, 128, 3, 2, 1, True),      # stride 2 with a residual: streamed kernel, taps inner
 ])
 def test_implicit_conv_matches_fp64(cuda, b, h, w, cin, cout, k, s, p, res):
     from toad_amd import ops
