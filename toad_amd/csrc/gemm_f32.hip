@@ -97,11 +97,6 @@ static const GemmCfg &cfg() {
         TOAD_ATTR(gemm_tn_pt_kernel, TP_SMEM);
         TOAD_ATTR(gemm_nt_f32_kernel, NT_SMEM);
         TOAD_ATTR(gemm_tn_f32_kernel, TN_SMEM);
-        TOAD_ATTR((gemm_nt_h2_narrow_kernel<2, 2, GATHER_NONE>), (NarrowCfgH2<2, 2>::SMEM));
-        TOAD_ATTR((gemm_nt_h2_narrow_kernel<1, 4, GATHER_NONE>), (NarrowCfgH2<1, 4>::SMEM));
-        TOAD_ATTR((gemm_nt_h2_narrow_kernel<2, 2, GATHER_CONV>), (NarrowCfgH2<2, 2>::SMEM));
-        TOAD_ATTR((gemm_nt_h2_narrow_kernel<1, 4, GATHER_CONV>), (NarrowCfgH2<1, 4>::SMEM));
-        TOAD_ATTR((gemm_nt_h2_narrow_kernel<2, 2, GATHER_STEM>), (NarrowCfgH2<2, 2>::SMEM));
         TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 2, GATHER_NONE>), (StreamCfg<2, 2>::SMEM));
         TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 4, GATHER_NONE>), (StreamCfg<2, 4>::SMEM));
         TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 2, GATHER_CONV>), (StreamCfg<2, 2>::SMEM));
@@ -110,6 +105,11 @@ static const GemmCfg &cfg() {
         TOAD_ATTR(conv3x3_h2_halo_kernel<2>, 160 * 1024);
         TOAD_ATTR(conv3x3_h2_halo_kernel<4>, 160 * 1024);
 #ifdef TOAD_AB_KNOBS
+        TOAD_ATTR((gemm_nt_h2_narrow_kernel<2, 2, GATHER_NONE>), (NarrowCfgH2<2, 2>::SMEM));
+        TOAD_ATTR((gemm_nt_h2_narrow_kernel<1, 4, GATHER_NONE>), (NarrowCfgH2<1, 4>::SMEM));
+        TOAD_ATTR((gemm_nt_h2_narrow_kernel<2, 2, GATHER_CONV>), (NarrowCfgH2<2, 2>::SMEM));
+        TOAD_ATTR((gemm_nt_h2_narrow_kernel<1, 4, GATHER_CONV>), (NarrowCfgH2<1, 4>::SMEM));
+        TOAD_ATTR((gemm_nt_h2_narrow_kernel<2, 2, GATHER_STEM>), (NarrowCfgH2<2, 2>::SMEM));
         TOAD_ATTR((gemm_nt_split_narrow_kernel<2, 2, GATHER_NONE>), (NarrowCfg<2, 2>::SMEM));
         TOAD_ATTR((gemm_nt_split_narrow_kernel<1, 4, GATHER_NONE>), (NarrowCfg<1, 4>::SMEM));
         TOAD_ATTR((gemm_nt_split_narrow_kernel<2, 2, GATHER_CONV>), (NarrowCfg<2, 2>::SMEM));
@@ -174,15 +174,17 @@ static int launch_narrow_t(const float *A, int64_t lda, const float *a_gmax, con
         return TOAD_OK;
     }
 #endif
-    using Cfg = NarrowCfgH2<RA, NB>;
-    const int tiles_m = (int)((M + Cfg::TM - 1) / Cfg::TM), tiles_n = (int)((N + Cfg::TN - 1) / Cfg::TN);
+    constexpr int TNW = NB * 32;         // tile width; <RA, NB> name round 1's tiles (512 x 64 / 256 x 128), the streamed kernels run 64-row wave tiles
+    const int tiles_n = (int)((N + TNW - 1) / TNW);
     unsigned short *planes = reinterpret_cast<unsigned short *>(w);
-    float *binv = reinterpret_cast<float *>(w + (size_t)tiles_n * Cfg::TN * (size_t)K * 4);
+    float *binv;
     // the streamed kernel walks an implicit convolution's k-stages channel-chunk outer, tap inner (gemm_stream.inc): its planes are split in that order
-    const bool stream = cfg().stream && K % (2 * BK) == 0;
+    const bool stream = cfg().stream;
     const int taps = (stream && MODE == GATHER_CONV) ? (int)(K / cg.C) : 1;
-    hipLaunchKernelGGL(split_planes_narrow_h2_kernel<NB>, dim3((tiles_n * Cfg::TN + 3) / 4), dim3(256), 0, st, W, ldw, planes, binv, (int)N, (int)K, tiles_n,
-                       taps, cg.C);
+    const int nk = (int)(K / BK), nkp = stream ? (nk + 1) & ~1 : nk;    // the streamed kernel walks k-stages in pairs: an odd count gets a zero stage
+    binv = reinterpret_cast<float *>(w + (size_t)tiles_n * TNW * (size_t)nkp * BK * 4);
+    hipLaunchKernelGGL(split_planes_narrow_h2_kernel<NB>, dim3((tiles_n * TNW + 3) / 4), dim3(256), 0, st, W, ldw, planes, binv, (int)N, (int)K, tiles_n,
+                       taps, cg.C, nkp);
     if (int rc = check_launch(what)) return rc;
     if (stream && MODE == GATHER_CONV && cfg().halo) {       // 3x3 / 1 / 1 with whole 256-pixel row blocks: the activation halo lives in LDS (gemm_stream.inc)
         const int W = cg.W, H = cg.H;
@@ -204,9 +206,15 @@ static int launch_narrow_t(const float *A, int64_t lda, const float *a_gmax, con
                            C, ldc, (int)M, (int)N, (int)K, bias, relu, addend, cg, y_gmax, stiles_m, tiles_n);
         return check_launch(what);
     }
+#ifdef TOAD_AB_KNOBS        // TOAD_NARROW_STREAM=0: the LDS-staged narrow kernel the streamed one replaced (same arithmetic; gemm_narrow.inc)
+    using Cfg = NarrowCfgH2<RA, NB>;
     hipLaunchKernelGGL((gemm_nt_h2_narrow_kernel<RA, NB, MODE>), dim3(PB_GRID), dim3(512), Cfg::SMEM, st, A, lda, a_gmax, planes, binv, C, ldc,
-                       (int)M, (int)N, (int)K, bias, relu, addend, cg, y_gmax, tiles_m, tiles_n);
+                       (int)M, (int)N, (int)K, bias, relu, addend, cg, y_gmax, (int)((M + Cfg::TM - 1) / Cfg::TM), tiles_n);
     return check_launch(what);
+#else
+    set_error("%s: internal: no narrow kernel selected", what);
+    return TOAD_EINVAL;
+#endif
 }
 
 static int narrow_res_kmax() { return cfg().narrow_res_kmax; }
