@@ -294,17 +294,32 @@ def time_allreduce(dp, dev, world: int, backend: str):
     return info
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout() -> None:
+    """Keep stdout for THE json line alone: file descriptor 1 is pointed at stderr for the rest of the run (RCCL prints a version
+    banner through C stdio when a communicator is created, libraries print notices), the original descriptor is kept for emit()."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
 def emit(out: dict) -> None:
-    """Print THE json line as the last thing on stdout. Libraries that write through C stdio (RCCL prints a version banner when a
-    communicator is created) sit in a buffer that is only flushed at exit when stdout is a pipe - i.e. after Python's own line;
-    flush it first."""
+    """Write THE json line - the only thing that reaches the caller's stdout (claim_stdout)."""
     import ctypes
     try:
-        ctypes.CDLL(None).fflush(None)
+        ctypes.CDLL(None).fflush(None)                       # whatever sits in C stdio buffers goes where fd 1 points now (stderr)
     except Exception:                                        # noqa: BLE001
         pass
     sys.stdout.flush()
-    print(json.dumps(out), flush=True)
+    line = (json.dumps(out) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.buffer.write(line); sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
 
 
 def run_config2(args, dev):
@@ -379,6 +394,7 @@ def main():
         return bench_extract.main()
     # `python bench.py --gpus N` started plainly: spawn the N ranks (torch.distributed.run, 127.0.0.1) and exit with their code
     launch.maybe_self_launch(__file__, sys.argv[1:], args.gpus, single_device=args.single_device)
+    claim_stdout()                                         # from here on only emit() writes to the caller's stdout
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -397,11 +413,11 @@ def main():
         n = args.patches or 100_000
         ms = time_dropin(n, args.steps, args.warmup, dev, host_reads=False)
         ms_h = time_dropin(n, args.steps, args.warmup, dev, host_reads=True)
-        print(json.dumps({"metric": f"drop-in train_loop body, {n}-patch bags", "value": round(1e3 / ms, 2), "unit": "slides/s", "n_gpus": 1,
+        emit({"metric": f"drop-in train_loop body, {n}-patch bags", "value": round(1e3 / ms, 2), "unit": "slides/s", "n_gpus": 1,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "ms_per_step_with_host_reads": round(ms_h, 4),
                           "higher_is_better": True, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "model(data, sex) + nn.CrossEntropyLoss x2 + loss.backward() + torch.optim.Adam.step() + zero_grad() "
-                                                 "(utils/core_utils_mtl_concat.py:206-234) on toad_amd.TOAD_fc_mtl_concat, resident bags"}}), flush=True)
+                                                 "(utils/core_utils_mtl_concat.py:206-234) on toad_amd.TOAD_fc_mtl_concat, resident bags"}})
         return
 
     from toad_amd import TOAD_fc_mtl_concat, ops

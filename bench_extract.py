@@ -30,7 +30,7 @@ if REPO not in sys.path:
 import torch
 import torch.distributed as dist
 
-from bench import C, MFMA_EQ_PEAK, SPLIT_TERMS, _physical_cores, emit
+from bench import C, MFMA_EQ_PEAK, SPLIT_TERMS, _physical_cores, claim_stdout, emit
 
 FLOP_PER_TILE = 8_562_671_616          # sum of 2*M*K*N over the 43 convolutions at 256x256 (stem K = 147), SURVEY 8d config 5: 8.56 GFLOP
 
@@ -81,6 +81,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     from toad_amd import launch
     launch.maybe_self_launch(__file__, sys.argv[1:], args.gpus)          # started plainly with --gpus N: spawn the N ranks
+    claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one process per GPU (or run this script plainly)")
