@@ -3,12 +3,14 @@
 // -fgpu-rdc), organised as:
 //   gemm_nt_f32.inc    generic 128x128 NT kernel; exact-fp32 persistent 256x256 NT kernel (v_mfma_f32_32x32x2_f32, the A/B arm);
 //                      the per-XCD tile plan, the shared epilogue, the K-split fix-up
-//   gemm_nt_split.inc  extractor convolutions (and the A/B arm TOAD_GEMM_H2=0): persistent 256x256 NT kernel on the bf16 pipe with x = h + m + l (six MFMA
-//                      terms = fp32-equivalent results), weight planes pre-split into the LDS image
-//   gemm_tn.inc        wgrad: generic, exact-fp32 persistent and SHIPPED split-bf16 persistent TN kernels; slab reduction; transpose
-//   gemm_h2.inc        SHIPPED MIL GEMMs (forward / dgrad / wgrad): persistent 256x256 kernels on the fp16 pipe with two-piece
-//                      operands (x*s = h + m, three MFMA terms, power-of-two scales from per-256-row abs-max arrays)
-//   gemm_narrow.inc    512x64 / 256x128 narrow-tile split-bf16 NT kernels with implicit convolution / stem gathers in the LDS-DMA
+//   gemm_nt_split.inc  A/B builds only (TOAD_GEMM_H2=0): round 1's persistent 256x256 NT kernel on the bf16 pipe with x = h + m + l (six MFMA
+//                      terms), weight planes pre-split into the LDS image
+//   gemm_tn.inc        wgrad: the generic TN kernel, slab reduction, transpose; round 1's exact-fp32 / split-bf16 persistent TN kernels (A/B builds only)
+//   gemm_h2.inc        SHIPPED MIL GEMMs (forward / dgrad / wgrad) and the extractor's wide convolutions: persistent 256x256 kernels on the
+//                      fp16 pipe with two-piece operands (x*s = h + m, three MFMA terms, power-of-two scales from per-256-row abs-max arrays)
+//   gemm_pt.inc        plane-tiled prepared bags: the splitter and the weight-gradient kernel that reads them by LDS-DMA + transposing LDS reads
+//   gemm_narrow.inc    the narrow-N weight-plane format (SHIPPED); the LDS-staged 512x64 / 256x128 narrow kernels (A/B builds only)
+//   gemm_stream.inc    SHIPPED narrow-N kernels of the extractor: A streamed through registers; 3x3 convolutions with the activation halo in LDS
 //   this file          shared constants, launch selection, the extern "C" entry points declared in include/toad_hip.h
 //
 // Two product shapes cover every GEMM on the path:
