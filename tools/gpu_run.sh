@@ -4,6 +4,7 @@
 #   ab:N          tools/ab_step.py on prepared and fp32 bags                         stats[:N]     rocprofv3 --kernel-trace --stats of the fused step
 #   pmc[:N]       SQ counter pass of the fused step                                  smoke         __graft_entry__.smoke()
 #   traffic[:N]   FETCH_SIZE / WRITE_SIZE passes of the pool kernels -> pool_traffic.json (copy to profiles/rNN_pool_traffic.json)
+#   bstats[:args] rocprofv3 --kernel-trace --stats of `python bench.py args`             ctraffic:"B H W Cin Cout k s p"  FETCH_SIZE of one convolution layer
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-run}; shift
@@ -28,6 +29,10 @@ for what in "$@"; do
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python $ROOT/tools/pmc_step.py ${arg:-100000} 8 > $OUT/prof.log 2>&1)
       python tools/summarize_rocprof.py $(find $OUT/prof -name "*kernel_stats.csv" | head -1) "$TAG fused step N=${arg:-100000} (8 steps, prepared bag)" > $OUT/kernel_stats.md 2>&1
       head -24 $OUT/kernel_stats.md ;;
+    bstats)         # rocprofv3 --kernel-trace --stats of the bench command itself (the summary the bench line's kernel times are checked against)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bprof -o p -- python $ROOT/bench.py ${arg:---steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0} > $OUT/bprof.json 2> $OUT/bprof.err)
+      python tools/summarize_rocprof.py $(find $OUT/bprof -name "*kernel_stats.csv" | head -1) "$TAG: rocprofv3 --kernel-trace --stats -- python bench.py ${arg:---steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0}" > $OUT/bench_kernel_stats.md 2>&1
+      head -16 $OUT/bench_kernel_stats.md; tail -c 300 $OUT/bprof.json ;;
     pmc)
       (cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE \
           --kernel-trace --output-format csv -d $OUT/pmc -o p -- python $ROOT/tools/pmc_step.py ${arg:-100000} 3 > $OUT/pmc.log 2>&1)
