@@ -37,3 +37,17 @@ def test_plain_start_spawns_the_ranks():
                        text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "LAUNCH_PROBE world=2 sum=3" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_bench_stdout_carries_only_the_json_line():
+    """bench.py's contract is ONE json line on stdout. Libraries print through C stdio (RCCL's version banner when a communicator is
+    created): claim_stdout() points fd 1 at stderr for the rest of the run and emit() writes to the saved descriptor."""
+    import json
+    import subprocess
+    code = ("import sys, os; sys.path.insert(0, %r); import bench; bench.claim_stdout(); print('python noise'); "
+            "os.write(1, b'fd-level noise\\n'); import ctypes; ctypes.CDLL(None).puts(b'C stdio noise'); bench.emit({'value': 1.5})" % REPO)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("\n") == 1 and json.loads(r.stdout) == {"value": 1.5}
+    for noise in ("python noise", "fd-level noise", "C stdio noise"):
+        assert noise in r.stderr
