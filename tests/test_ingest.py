@@ -70,13 +70,14 @@ def test_device_bags_match_and_half_precision_is_upcast(cuda):
 
 @pytest.mark.gpu
 def test_copies_overlap_with_compute(cuda):
-    """8 bags of 50k patches (205 MB each): consuming them through the prefetcher while the model trains must take
-    clearly less than copy time + compute time (i.e. the H2D copies hide behind the kernels)."""
+    """24 bags of 50k patches (205 MB each): consuming them through the prefetcher while the model trains must take clearly less
+    than the reference's blocking-copy-then-step loop (i.e. the H2D copies hide behind the kernels). 24, not 8: a new prefetcher's
+    copy stream starts with an empty allocator pool, and its first 205 MB hipMalloc (5-6 ms) is a quarter of an 8-bag run."""
     from toad_amd import TOAD_fc_mtl_concat
     from toad_amd.dp import SlideShardedDP
     from toad_amd.ingest import BagPrefetcher
     torch.manual_seed(0)
-    n_bags, rows = 8, 50000
+    n_bags, rows = 24, 50000
     host = [torch.randn(rows, 1024).pin_memory() for _ in range(2)]
     recs = [(host[i % 2], i % 18, i % 2, 0.0) for i in range(n_bags)]
     model = TOAD_fc_mtl_concat(n_classes=18); model.relocate()
@@ -88,22 +89,21 @@ def test_copies_overlap_with_compute(cuda):
             dp.step([(bag, sex, label, site)], 1)
         torch.cuda.synchronize(); return time.perf_counter() - t0
 
-    consume(2)                                   # warm-up (allocator, kernels)
-    t_overlap = consume(3)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for src, *_ in recs:
-        src.to(cuda, non_blocking=False)
-    torch.cuda.synchronize(); t_copy = time.perf_counter() - t0
-    dev = host[0].to(cuda)
-    lab = torch.tensor([1], device=cuda); sit = torch.tensor([0], device=cuda); sx = torch.zeros(1, device=cuda)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(n_bags):
-        dp.step([(dev, sx, lab, sit)], 1)
-    torch.cuda.synchronize(); t_compute = time.perf_counter() - t0
-    print(f"copy {t_copy*1e3:.1f} ms  compute {t_compute*1e3:.1f} ms  pipelined {t_overlap*1e3:.1f} ms")
-    # at least 30 % of the shorter phase must hide behind the longer one (measured: 32.8 ms against 29.0 + 17.2; the bound
-    # is 41 ms, loose enough for a noisy box, and a serialised pipeline at 46 ms still fails it)
-    assert t_overlap < t_copy + t_compute - 0.3 * min(t_copy, t_compute), (t_copy, t_compute, t_overlap)
+    def serial():                                # the reference's loop: blocking copy, then the step (utils/core_utils_mtl_concat.py:201-204)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for src, label, site, sex in recs:
+            bag = src.to(cuda, non_blocking=False)
+            dp.step([(bag, torch.tensor([sex], device=cuda), torch.tensor([label], device=cuda), torch.tensor([site], device=cuda))], 1)
+        torch.cuda.synchronize(); return time.perf_counter() - t0
+
+    consume(2); serial()                         # warm-up (allocator, kernels)
+    # interleaved trials, best of three each: one slow trial on a shared box (host threads, PCIe) must not decide the test
+    t_pipe, t_serial = [], []
+    for _ in range(3):
+        t_serial.append(serial()); t_pipe.append(consume(3))
+    print(f"serial {min(t_serial)*1e3:.1f} ms  pipelined {min(t_pipe)*1e3:.1f} ms  (all: {t_serial} {t_pipe})")
+    # copies are ~3.6 ms and steps ~1.4 ms per bag: fully hidden the pipeline takes ~0.77 of the serial loop; 0.92 fails a serialised one
+    assert min(t_pipe) < 0.92 * min(t_serial), (t_serial, t_pipe)
 
 
 @pytest.mark.gpu
