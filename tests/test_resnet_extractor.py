@@ -154,6 +154,8 @@ def test_linear_act_res_matches_fp64(cuda, m, k, n, res, act):
     (4, 16, 16, 64, 192, 3, 1, 1, True),      # halo kernel with a residual and a ragged second column tile
     (1, 128, 128, 64, 32, 3, 1, 1, False),    # halo kernel at its widest image (two rows per tile, one workgroup per CU), Cout below a tile
     (3, 8, 8, 64, 64, 3, 1, 1, False),        # image shorter than a 256-pixel row block: streamed kernel
+    (2, 64, 8, 64, 128, 3, 1, 1, True),       # halo kernel at its narrowest image (32 rows per tile), residual
+    (1, 4, 128, 32, 128, 3, 1, 1, False),     # halo kernel, widest image with 128 output channels, a single 32-channel chunk (odd stage count: 9)
     (2, 16, 16, 96, 64, 3, 1, 1, False),      # 27 k-stages (odd): the LDS-staged narrow kernel
     (1, 40, 24, 64, 128, 3, 2, 1, True),      # stride 2 with a residual: streamed kernel, taps inner
 ])
