@@ -2,12 +2,14 @@
 // inference form, as the producer of the [N,1024] bags the MIL path consumes (BASELINE config 5).
 //
 // Design for gfx950: activations live in HBM as NHWC fp32, so every convolution is the NT product the MIL trunk
-// already runs — Y[M, Cout] = act(cols[M, K] . Wf[Cout, K]^T + bf (+ residual)) with M = B*Ho*Wo pixels — on the
-// same persistent split-bf16 MFMA kernel (gemm_f32.hip; fp32-accurate, so the extractor keeps the 1e-4 parity bar).
-// Batch-norm (eval form) is folded into Wf / bf on the host; ReLU and the bottleneck's residual add ride in the GEMM
-// epilogue. 1x1 stride-1 convolutions need no data movement at all (cols == the NHWC activation); 3x3 and strided
-// 1x1 convolutions gather their K = kh*kw*Cin columns with the HBM-bound kernels below (16-B lanes, coalesced on
-// the channel dimension); the 7x7 stem gathers straight from the caller's NCHW tiles.
+// already runs — Y[M, Cout] = act(cols[M, K] . Wf[Cout, K]^T + bf (+ residual)) with M = B*Ho*Wo pixels — in the
+// same fp16 two-piece MFMA arithmetic (gemm_f32.hip; fp32-accurate, so the extractor keeps the 1e-4 parity bar):
+// Cout >= 256 on the persistent 256x256 kernel, narrower layers, short-K residual expansions, the stem and the 3x3
+// convolutions on the kernels of gemm_stream.inc (A streamed through registers; stride-1 3x3 with the activation halo
+// in LDS) - those never materialise cols. Batch-norm (eval form) is folded into Wf / bf on the host; ReLU and the
+// bottleneck's residual add ride in the GEMM epilogue. 1x1 stride-1 convolutions need no data movement at all (cols ==
+// the NHWC activation); the explicit gathers below (16-B lanes, coalesced on the channel dimension) remain for strided
+// 1x1 convolutions, for small batches of the 256-channel 3x3, and as API entry points.
 #include "common.h"
 
 namespace toad {
@@ -311,9 +313,9 @@ extern "C" int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float 
             TOAD_TRY(ext_linear(x, gx, weights[ci], biases[ci], nullptr, t1, g1, Mi, inpl, pl, TOAD_ACT_RELU, gws, gcap, st, what));
             // conv2 3x3 stride s + BN + ReLU (:42-44)
             float *t2 = other(x, t1, nullptr);
-            // gather inside the GEMM's LDS-DMA, no cols buffer: always for the narrow layers; for 256 output channels (two
-            // 128-column tiles per 256 rows, A gathered and split twice) only when there are enough tiles to fill the chip
-            // twice over - otherwise im2col + the 256x256 kernel with its K-split is faster (measured at B = 64 vs 512)
+            // implicit convolution (halo in LDS for stride 1, streamed taps for stride 2), no cols buffer: always for the narrow
+            // layers; for 256 output channels (two 128-column tiles per 256 pixels) only when there are enough tiles to fill
+            // the chip's 512 workgroup slots - otherwise im2col + the 256x256 kernel with its K-split is faster (measured at B = 64 vs 512)
             const bool implicit = implicit_conv_enabled() && (pl <= 128 || (pl <= 256 && (Mo / 256) * ((pl + 127) / 128) >= 512));
             float *g2 = slot();
             if (implicit) {
