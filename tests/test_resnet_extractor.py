@@ -125,7 +125,8 @@ def test_stem_gather_maxpool_avgpool_bit_exact(cuda, b, h, w):
 @pytest.mark.parametrize("m,k,n,res,act", [(4096, 64, 64, False, 1), (1000, 576, 64, False, 1), (777, 128, 512, True, 1),
                                            (2048, 2304, 256, False, 1), (300, 160, 64, False, 1), (512, 256, 1024, True, 0),
                                            # streamed kernels with more tiles than workgroups (cross-tile prefetch, one weight chunk per tile), ragged M
-                                           (140001, 64, 128, True, 1), (200003, 64, 64, False, 1), (133000, 192, 100, False, 0)])
+                                           (140001, 64, 128, True, 1), (200003, 64, 64, False, 1), (133000, 192, 100, False, 0),
+                                           (3000, 32, 256, True, 1)])      # K = 32 with a residual: narrow tiles, two column tiles, padded planes
 def test_linear_act_res_matches_fp64(cuda, m, k, n, res, act):
     from toad_amd import ops
     g = torch.Generator().manual_seed(m + k + n)
@@ -158,6 +159,8 @@ def test_linear_act_res_matches_fp64(cuda, m, k, n, res, act):
     (1, 4, 128, 32, 128, 3, 1, 1, False),     # halo kernel, widest image with 128 output channels, a single 32-channel chunk (odd stage count: 9)
     (2, 16, 16, 96, 64, 3, 1, 1, False),      # 27 k-stages (odd): the LDS-staged narrow kernel
     (1, 40, 24, 64, 128, 3, 2, 1, True),      # stride 2 with a residual: streamed kernel, taps inner
+    (1, 16, 16, 32, 256, 1, 1, 0, False),     # K = 32: one real k-stage + the zero stage, two column tiles - the padded planes are 4 x 64 bytes per
+                                              # weight row and once overran the workspace's plane area into the abs-max scalar (found by tools/conv_fuzz.py)
 ])
 def test_implicit_conv_matches_fp64(cuda, b, h, w, cin, cout, k, s, p, res):
     from toad_amd import ops

@@ -470,7 +470,9 @@ using namespace toad;
 extern "C" size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K) {
     (void)M;
     // one 256x256 fp32 slab per persistent block (64 MiB) + the three bf16 planes of the weight operand
-    const size_t tiles_n = (size_t)((N + PB - 1) / PB), kpad = (size_t)((K + BK - 1) / BK * BK);
+    // K rounded up to an EVEN number of 32-deep stages: the streamed narrow kernels walk stages in pairs and their planes carry a zero
+    // stage when the count is odd (at K = 32 that doubles the planes: 4 x 64 bytes per weight row > the 6 x 32 reserved before)
+    const size_t tiles_n = (size_t)((N + PB - 1) / PB), kpad = (size_t)((K + 2 * BK - 1) / (2 * BK) * (2 * BK));
     // (the h2 path needs 4 bytes per weight element + inverse scales + the abs-max array of A; the 6-byte planes of the older split cover it)
     return (size_t)PB_GRID * PB * PB * sizeof(float) + tiles_n * PB * kpad * 6 + tiles_n * PB * sizeof(float) +
            (size_t)(h2_nblk(M > 0 ? M : 1) + 64) * sizeof(float) + 256;
@@ -520,7 +522,7 @@ extern "C" int toad_linear_act_fwd_f32(const float *X, const float *W, const flo
 // x_gmax: device scalar max |X| of the whole activation (NULL: measured here, one extra read); y_gmax: device scalar that receives
 // max |Y| by atomic max (the caller zeroed it; NULL: not wanted). One tensor-wide power-of-two scale per activation: gemm_narrow.inc.
 static float *ext_scratch_scalar(void *ws, int64_t M, int64_t N, int64_t K) {          // a float inside the workspace's abs-max area
-    const size_t tiles_n = (size_t)((N + PB - 1) / PB), kpad = (size_t)((K + BK - 1) / BK * BK);
+    const size_t tiles_n = (size_t)((N + PB - 1) / PB), kpad = (size_t)((K + 2 * BK - 1) / (2 * BK) * (2 * BK));        // as toad_linear_ws_bytes
     return reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + (size_t)PB_GRID * PB * PB * sizeof(float) + tiles_n * PB * kpad * 6 + tiles_n * PB * sizeof(float)) + 8;
 }
 int toad::ext_linear(const float *X, const float *x_gmax, const float *W, const float *bias, const float *residual, float *Y, float *y_gmax,
