@@ -1,5 +1,5 @@
-"""Random-shape parity sweep of the extractor's convolution / residual-GEMM entry points against fp64 (not part of the test suite: run on a GPU box,
-`python tools/conv_fuzz.py [cases] [seed]`). Exercises the kernel selection of gemm_f32.hip: halo (stride-1 3x3 on power-of-two widths), streamed
+"""Random-shape parity sweep of the extractor's convolution / residual-GEMM entry points against fp64 (run on a GPU box (tests/test_gpu_fuzz.py runs a short fixed-seed sweep),
+`python tests/fuzz_conv.py [cases] [seed]`). Exercises the kernel selection of gemm_f32.hip: halo (stride-1 3x3 on power-of-two widths), streamed
 (everything else narrow, odd stage counts, strides), 256x256 (wide), with ragged M / Cout, several images per tile and tiles per image."""
 import os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

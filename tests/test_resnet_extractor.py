@@ -160,7 +160,7 @@ def test_linear_act_res_matches_fp64(cuda, m, k, n, res, act):
     (2, 16, 16, 96, 64, 3, 1, 1, False),      # 27 k-stages (odd): the LDS-staged narrow kernel
     (1, 40, 24, 64, 128, 3, 2, 1, True),      # stride 2 with a residual: streamed kernel, taps inner
     (1, 16, 16, 32, 256, 1, 1, 0, False),     # K = 32: one real k-stage + the zero stage, two column tiles - the padded planes are 4 x 64 bytes per
-                                              # weight row and once overran the workspace's plane area into the abs-max scalar (found by tools/conv_fuzz.py)
+                                              # weight row and once overran the workspace's plane area into the abs-max scalar (found by tests/fuzz_conv.py)
 ])
 def test_implicit_conv_matches_fp64(cuda, b, h, w, cin, cout, k, s, p, res):
     from toad_amd import ops
