@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtoad_hip.so")
 SOURCES = ["capi.hip", "gemm_f32.hip", "gated_pool.hip", "heads.hip", "step.hip", "conv.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(REPO, "include", "toad_hip.h")] + \
-    [os.path.join(CSRC, f) for f in ("gemm_nt_f32.inc", "gemm_nt_split.inc", "gemm_tn.inc", "gemm_h2.inc", "gemm_pt.inc", "gemm_narrow.inc", "gemm_stream.inc")]
+    [os.path.join(CSRC, f) for f in ("gemm_nt_f32.inc", "gemm_tn.inc", "gemm_h2.inc", "gemm_pt.inc", "gemm_narrow.inc", "gemm_stream.inc")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
          "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 
@@ -28,8 +28,8 @@ def _stale(obj: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "") -> str:
-    """Build libtoad_hip{tag}.so. `defines` / `tag` produce an A/B variant next to the shipped library (e.g.
-    defines=("TOAD_H2_C_SPLIT",), tag="_csplit"; select it at run time with TOAD_HIP_LIB=<path>)."""
+    """Build libtoad_hip{tag}.so. `defines` / `tag` build an experiment variant next to the shipped library (tools/ab/README.md; select it
+    at run time with TOAD_HIP_LIB=<path>); the sources under csrc/ carry no variant switches of their own."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     lib = LIB.replace(".so", tag + ".so")
     objs = []
@@ -55,7 +55,4 @@ def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "") 
 
 
 if __name__ == "__main__":
-    if "--csplit" in sys.argv:          # A/B arm: plain-C operand split instead of the v_fma_mix asm block (same results)
-        print(build(force="--force" in sys.argv, defines=("TOAD_H2_C_SPLIT",), tag="_csplit"))
-    else:
-        print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv))

@@ -78,11 +78,7 @@ __device__ __forceinline__ float h2_absmax4(f32x4 v) {
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 // streaming store: the line is not kept dirty in L2 for the next kernel to flush (GEMM outputs are consumed by the NEXT launch)
 __device__ __forceinline__ void st4s(float *p, f32x4 v) {
-#ifdef TOAD_PLAIN_STORES
-    st4(p, v);
-#else
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
-#endif
 }
 
 // how the bag (the A operand of the first Linear, the B operand of its weight gradient) lies in memory

@@ -193,12 +193,7 @@ static bool make_plan(int B, int H, int W, NetPlan &p) {
 }
 
 static int implicit_conv_enabled() {
-#ifdef TOAD_AB_KNOBS        // A/B builds only: TOAD_CONV_IMPLICIT=0 selects the explicit im2col + GEMM path (bit-identical results)
-    static const int v = [] { const char *e = getenv("TOAD_CONV_IMPLICIT"); return e ? atoi(e) : 1; }();
-    return v;
-#else
     return 1;
-#endif
 }
 
 static inline size_t align2m(size_t x) { return (x + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1); }

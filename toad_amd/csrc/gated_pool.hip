@@ -53,11 +53,7 @@ __device__ __forceinline__ float groups_sum(float v) {
 // (bench.py, N=100k) the fused forward drops 105.6 -> 80.7 us and the backward 182 -> 167 us;
 // -DTOAD_POOL_PLAIN_LOADS rebuilds the plain-load arm for A/B runs.
 __device__ __forceinline__ f32x4 ld4s(const float *p) {
-#ifdef TOAD_POOL_PLAIN_LOADS
-    return ld4(p);
-#else
     return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
-#endif
 }
 
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
@@ -624,14 +620,8 @@ __global__ __launch_bounds__(256) void bwd_partial_reduce_kernel(const float *__
 // (rocprofv3, 100k patches: forward 84 -> 75 us = 6.85 TB/s, backward 172 -> 140 us; three per CU is slower again, profiles/r02ba_*).
 static int pool_grid(int64_t N, bool bwd = false) {
     const int64_t ntiles = (N + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP;
-#ifdef TOAD_AB_KNOBS        // tuning knobs of A/B builds only (toad_amd.build.build(defines=("TOAD_AB_KNOBS",), ...))
-    static const int64_t cap_f = [] { const char *e = getenv("TOAD_POOL_GRID"); const int64_t v = e ? atoll(e) : 512; return v < 1 ? 512 : v; }();
-    static const int64_t cap_b = [] { const char *e = getenv("TOAD_POOL_BWD_GRID"); const int64_t v = e ? atoll(e) : 512; return v < 1 ? 512 : v; }();
-    const int64_t cap = bwd ? cap_b : cap_f;
-#else
     (void)bwd;
     const int64_t cap = 512;
-#endif
     return (int)(ntiles < cap ? ntiles : cap);
 }
 

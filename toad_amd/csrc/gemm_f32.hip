@@ -1,26 +1,26 @@
 // gemm_f32.hip — the fp32-accurate MFMA GEMMs of libtoad_hip.so (gfx950): the Linear layers of TOAD's MIL path and the
 // convolutions-as-GEMMs of the feature extractor. One translation unit (kernels and launchers must share a TU without
 // -fgpu-rdc), organised as:
-//   gemm_nt_f32.inc    generic 128x128 NT kernel; exact-fp32 persistent 256x256 NT kernel (v_mfma_f32_32x32x2_f32, the A/B arm);
-//                      the per-XCD tile plan, the shared epilogue, the K-split fix-up
-//   gemm_nt_split.inc  A/B builds only (TOAD_GEMM_H2=0): round 1's persistent 256x256 NT kernel on the bf16 pipe with x = h + m + l (six MFMA
-//                      terms), weight planes pre-split into the LDS image
-//   gemm_tn.inc        wgrad: the generic TN kernel, slab reduction, transpose; round 1's exact-fp32 / split-bf16 persistent TN kernels (A/B builds only)
-//   gemm_h2.inc        SHIPPED MIL GEMMs (forward / dgrad / wgrad) and the extractor's wide convolutions: persistent 256x256 kernels on the
+//   gemm_nt_f32.inc    generic exact-fp32 128x128 NT kernel (the fallback for shapes the persistent kernels do not take); the per-XCD tile
+//                      plan and the shared epilogue of the persistent kernels
+//   gemm_tn.inc        wgrad: the generic exact-fp32 TN kernel, the split-M plan, slab reduction, transpose
+//   gemm_h2.inc        the MIL GEMMs (forward / dgrad / wgrad) and the extractor's wide convolutions: persistent 256x256 kernels on the
 //                      fp16 pipe with two-piece operands (x*s = h + m, three MFMA terms, power-of-two scales from per-256-row abs-max arrays)
 //   gemm_pt.inc        plane-tiled prepared bags: the splitter and the weight-gradient kernel that reads them by LDS-DMA + transposing LDS reads
-//   gemm_narrow.inc    the narrow-N weight-plane format (SHIPPED); the LDS-staged 512x64 / 256x128 narrow kernels (A/B builds only)
-//   gemm_stream.inc    SHIPPED narrow-N kernels of the extractor: A streamed through registers; 3x3 convolutions with the activation halo in LDS
+//   gemm_narrow.inc    the narrow-N weight-plane format, convolution geometry and gather modes of the extractor
+//   gemm_stream.inc    narrow-N kernels of the extractor: A streamed through registers; 3x3 convolutions with the activation halo in LDS
 //   this file          shared constants, launch selection, the extern "C" entry points declared in include/toad_hip.h
+// (Round 1's exact-fp32 / split-bf16 persistent kernels and the LDS-staged narrow kernels were A/B arms; they left the tree in round 4 -
+//  tools/ab/README.md names the commit that still holds them.)
 //
 // Two product shapes cover every GEMM on the path:
 //   gemm_nt : C[M,N] = epi(A[M,K] . B[N,K]^T)        both operands reduction-contiguous
 //             forward  Y = act(X W^T + b)             models/model_toad.py:59,62,21,25
-//             dgrad    dX = (dY (W^T)^T + add)*mask   with WT = W^T materialised once (2 MB)
+//             dgrad    dX = (dY (W^T)^T + add)*mask   W^T read transposed in place by the plane splitter
 //   gemm_tn : C[I,J] = sum_m A[m,I] . B[m,J]         both operands reduction-strided
 //             wgrad    dW = dY^T X, split over m, deterministic slab reduction
 // Why not plain bf16: parity with the reference's PyTorch-CPU path is 1e-4 on fp32 outputs and bf16 operands miss it
-// (1e-3..6e-3); gfx950 has no TF32/xf32. DESIGN.md 4 and 9 give the arithmetic and the measurements.
+// (1e-3..6e-3); gfx950 has no TF32/xf32. DESIGN.md 4 gives the arithmetic and the measurements.
 #include "common.h"
 
 #include <stdlib.h>
@@ -50,7 +50,6 @@ __device__ __forceinline__ bool map_tile(int tiles_m, int tiles_n, int &tm, int 
 }
 
 #include "gemm_nt_f32.inc"
-#include "gemm_nt_split.inc"
 #include "gemm_tn.inc"
 #include "gemm_h2.inc"
 #include "gemm_pt.inc"
@@ -60,32 +59,16 @@ __device__ __forceinline__ bool map_tile(int tiles_m, int tiles_n, int &tm, int 
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-// One-time initialisation of this translation unit: kernel attributes (dynamic LDS sizes) and the dispatch configuration.
-// The shipped library has ONE arithmetic per product shape and reads no environment variable on any dispatch path; a build
-// with -DTOAD_AB_KNOBS (toad_amd.build.build(defines=("TOAD_AB_KNOBS",), tag="_ab"), selected at run time with TOAD_HIP_LIB)
-// additionally compiles round 1's exact-fp32 / split-bf16 arms of the MIL GEMMs and lets TOAD_GEMM_* / TOAD_EXTRACT_H2 /
-// TOAD_NARROW_RES_KMAX choose them, for A/B measurements. std::call_once makes the first call from any thread complete the
+// One-time initialisation of this translation unit: kernel attributes (dynamic LDS sizes). The library has ONE arithmetic per
+// product shape and reads no environment variable anywhere; std::call_once makes the first call from any thread complete the
 // attribute calls before any launch (PyTorch runs backward on its own thread; the ingest workers are threads too).
-struct GemmCfg { int narrow, narrow_res_kmax, h2, big, split, ext_h2, stream, halo; };
-#ifdef TOAD_AB_KNOBS
-static int ab_knob(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
-#else
-static constexpr int ab_knob(const char *, int dflt) { return dflt; }
-#endif
-static GemmCfg g_cfg;
+// Residual GEMMs with a reduction of at most this many elements run on the narrow (streamed) tiles whatever their width: measured
+// (tools/gemm_shape_bench.py, same box) M=262144 K=64 N=256 +residual 170 -> 133 us; K=128 equal, K=256 slower (A is re-split per
+// 128-column tile)
+constexpr int kNarrowResKmax = 64;
 static std::once_flag g_cfg_once;
-static const GemmCfg &cfg() {
+static void cfg() {
     std::call_once(g_cfg_once, [] {
-        g_cfg.narrow = ab_knob("TOAD_GEMM_NARROW", 1);
-        // measured (tools/gemm_shape_bench.py, same box): M=262144 K=64 N=256 +residual 170 -> 133 us on the 256x128 narrow tiles
-        // (16 residual rows in flight per wave); K=128 equal, K=256 slower (A is re-split per 128-column tile) -> 64
-        g_cfg.narrow_res_kmax = ab_knob("TOAD_NARROW_RES_KMAX", 64);
-        g_cfg.h2 = ab_knob("TOAD_GEMM_H2", 1);
-        g_cfg.big = ab_knob("TOAD_GEMM_BIG", 1);
-        g_cfg.split = ab_knob("TOAD_GEMM_SPLIT", 1);
-        g_cfg.ext_h2 = ab_knob("TOAD_EXTRACT_H2", 1);
-        g_cfg.stream = ab_knob("TOAD_NARROW_STREAM", 1);
-        g_cfg.halo = ab_knob("TOAD_CONV_HALO", 1);
 #define TOAD_ATTR(K, BYTES) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES)
 #define TOAD_H2_ATTR(P, A_, M_) TOAD_ATTR((gemm_nt_h2_big_kernel<P, A_, M_, 0>), H2_SMEM)
         TOAD_H2_ATTR(false, false, 0); TOAD_H2_ATTR(false, false, 1); TOAD_H2_ATTR(false, false, 2);
@@ -106,27 +89,9 @@ static const GemmCfg &cfg() {
         TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 2, GATHER_STEM>), (StreamCfg<2, 2>::SMEM));
         TOAD_ATTR(conv3x3_h2_halo_kernel<2>, 160 * 1024);
         TOAD_ATTR(conv3x3_h2_halo_kernel<4>, 160 * 1024);
-#ifdef TOAD_AB_KNOBS
-        TOAD_ATTR((gemm_nt_h2_narrow_kernel<2, 2, GATHER_NONE>), (NarrowCfgH2<2, 2>::SMEM));
-        TOAD_ATTR((gemm_nt_h2_narrow_kernel<1, 4, GATHER_NONE>), (NarrowCfgH2<1, 4>::SMEM));
-        TOAD_ATTR((gemm_nt_h2_narrow_kernel<2, 2, GATHER_CONV>), (NarrowCfgH2<2, 2>::SMEM));
-        TOAD_ATTR((gemm_nt_h2_narrow_kernel<1, 4, GATHER_CONV>), (NarrowCfgH2<1, 4>::SMEM));
-        TOAD_ATTR((gemm_nt_h2_narrow_kernel<2, 2, GATHER_STEM>), (NarrowCfgH2<2, 2>::SMEM));
-        TOAD_ATTR((gemm_nt_split_narrow_kernel<2, 2, GATHER_NONE>), (NarrowCfg<2, 2>::SMEM));
-        TOAD_ATTR((gemm_nt_split_narrow_kernel<1, 4, GATHER_NONE>), (NarrowCfg<1, 4>::SMEM));
-        TOAD_ATTR((gemm_nt_split_narrow_kernel<2, 2, GATHER_CONV>), (NarrowCfg<2, 2>::SMEM));
-        TOAD_ATTR((gemm_nt_split_narrow_kernel<1, 4, GATHER_CONV>), (NarrowCfg<1, 4>::SMEM));
-        TOAD_ATTR((gemm_nt_split_narrow_kernel<2, 2, GATHER_STEM>), (NarrowCfg<2, 2>::SMEM));
-        TOAD_ATTR(gemm_nt_split_big_kernel, SP_SMEM);
-        TOAD_ATTR(gemm_nt_f32_big_kernel, PB_SMEM);
-        TOAD_ATTR(gemm_tn_f32_big_kernel, PB_SMEM);
-        TOAD_ATTR(gemm_tn_split_big_kernel, PB_SMEM);
-#endif
 #undef TOAD_ATTR
     });
-    return g_cfg;
 }
-static int narrow_enabled() { return cfg().narrow; }
 
 // max |x| over n floats -> out[0] (bit pattern of a non-negative float, zeroed here): the tensor-wide abs-max a narrow / extractor GEMM
 // scales its A operand with when no producer handed one over (the per-op entry points; inside toad_resnet50_trunc_fwd_f32 every
@@ -159,36 +124,18 @@ static int launch_narrow_t(const float *A, int64_t lda, const float *a_gmax, con
                            hipStream_t st, const char *what) {
     (void)cfg();
     char *w = reinterpret_cast<char *>(ws) + (size_t)PB_GRID * PB * PB * sizeof(float);
-#ifdef TOAD_AB_KNOBS        // TOAD_EXTRACT_H2=0: round 1's split-bf16 narrow kernel (six MFMA terms)
-    if (!cfg().ext_h2) {
-        using Cfg = NarrowCfg<RA, NB>;
-        const int tiles_m = (int)((M + Cfg::TM - 1) / Cfg::TM), tiles_n = (int)((N + Cfg::TN - 1) / Cfg::TN);
-        unsigned short *planes = reinterpret_cast<unsigned short *>(w);
-        const int64_t pthreads = (int64_t)tiles_n * (K / BK) * Cfg::TN * 4;
-        int pgrid = (int)((pthreads + 255) / 256);
-        if (pgrid > 4096) pgrid = 4096;
-        hipLaunchKernelGGL(split_planes_narrow_kernel<NB>, dim3(pgrid), dim3(256), 0, st, W, ldw, planes, (int)N, (int)K, tiles_n);
-        if (int rc = check_launch(what)) return rc;
-        hipLaunchKernelGGL((gemm_nt_split_narrow_kernel<RA, NB, MODE>), dim3(PB_GRID), dim3(512), Cfg::SMEM, st, A, lda, planes, C, ldc,
-                           (int)M, (int)N, (int)K, bias, relu, addend, cg, tiles_m, tiles_n);
-        if (int rc = check_launch(what)) return rc;
-        if (y_gmax) return launch_gmax(C, M * ldc, y_gmax, st, what);
-        return TOAD_OK;
-    }
-#endif
-    constexpr int TNW = NB * 32;         // tile width; <RA, NB> name round 1's tiles (512 x 64 / 256 x 128), the streamed kernels run 64-row wave tiles
+    constexpr int TNW = NB * 32;         // tile width (RA only names the instantiation; the streamed kernels run 64-row wave tiles)
     const int tiles_n = (int)((N + TNW - 1) / TNW);
     unsigned short *planes = reinterpret_cast<unsigned short *>(w);
     float *binv;
     // the streamed kernel walks an implicit convolution's k-stages channel-chunk outer, tap inner (gemm_stream.inc): its planes are split in that order
-    const bool stream = cfg().stream;
-    const int taps = (stream && MODE == GATHER_CONV) ? (int)(K / cg.C) : 1;
-    const int nk = (int)(K / BK), nkp = stream ? (nk + 1) & ~1 : nk;    // the streamed kernel walks k-stages in pairs: an odd count gets a zero stage
+    const int taps = MODE == GATHER_CONV ? (int)(K / cg.C) : 1;
+    const int nk = (int)(K / BK), nkp = (nk + 1) & ~1;                  // the streamed kernel walks k-stages in pairs: an odd count gets a zero stage
     binv = reinterpret_cast<float *>(w + (size_t)tiles_n * TNW * (size_t)nkp * BK * 4);
     hipLaunchKernelGGL(split_planes_narrow_h2_kernel<NB>, dim3((tiles_n * TNW + 3) / 4), dim3(256), 0, st, W, ldw, planes, binv, (int)N, (int)K, tiles_n,
                        taps, cg.C, nkp);
     if (int rc = check_launch(what)) return rc;
-    if (stream && MODE == GATHER_CONV && cfg().halo) {       // 3x3 / 1 / 1 with whole 256-pixel row blocks: the activation halo lives in LDS (gemm_stream.inc)
+    if (MODE == GATHER_CONV) {       // 3x3 / 1 / 1 with whole 256-pixel row blocks: the activation halo lives in LDS (gemm_stream.inc)
         const int W = cg.W, H = cg.H;
         const bool shape = cg.kw == 3 && K == 9 * (int64_t)cg.C && cg.stride == 1 && cg.pad == 1 && cg.Ho == H && cg.Wo == W && W >= 8 && W <= 128 &&
                            (W & (W - 1)) == 0 && H % (256 / W) == 0 && cg.C % BK == 0 && M % 256 == 0;
@@ -200,37 +147,25 @@ static int launch_narrow_t(const float *A, int64_t lda, const float *a_gmax, con
             return check_launch(what);
         }
     }
-    if (stream) {                        // A streamed through registers (gemm_stream.inc): wave tile 64 x 64 / 64 x 128 instead of 32 x 64 / 32 x 128
-        constexpr int SRA = 2;
-        using SCfg = StreamCfg<SRA, NB>;
-        const int stiles_m = (int)((M + SCfg::TM - 1) / SCfg::TM);
-        hipLaunchKernelGGL((gemm_nt_h2_stream_kernel<SRA, NB, MODE>), dim3(SCfg::WG_PER_CU * PB_GRID), dim3(SCfg::THREADS), SCfg::SMEM, st, A, lda, a_gmax, planes, binv,
-                           C, ldc, (int)M, (int)N, (int)K, bias, relu, addend, cg, y_gmax, stiles_m, tiles_n);
-        return check_launch(what);
-    }
-#ifdef TOAD_AB_KNOBS        // TOAD_NARROW_STREAM=0: the LDS-staged narrow kernel the streamed one replaced (same arithmetic; gemm_narrow.inc)
-    using Cfg = NarrowCfgH2<RA, NB>;
-    hipLaunchKernelGGL((gemm_nt_h2_narrow_kernel<RA, NB, MODE>), dim3(PB_GRID), dim3(512), Cfg::SMEM, st, A, lda, a_gmax, planes, binv, C, ldc,
-                       (int)M, (int)N, (int)K, bias, relu, addend, cg, y_gmax, (int)((M + Cfg::TM - 1) / Cfg::TM), tiles_n);
+    // A streamed through registers (gemm_stream.inc): wave tile 64 x 64 / 64 x 128
+    constexpr int SRA = 2;
+    using SCfg = StreamCfg<SRA, NB>;
+    const int stiles_m = (int)((M + SCfg::TM - 1) / SCfg::TM);
+    hipLaunchKernelGGL((gemm_nt_h2_stream_kernel<SRA, NB, MODE>), dim3(SCfg::WG_PER_CU * PB_GRID), dim3(SCfg::THREADS), SCfg::SMEM, st, A, lda, a_gmax, planes, binv,
+                       C, ldc, (int)M, (int)N, (int)K, bias, relu, addend, cg, y_gmax, stiles_m, tiles_n);
     return check_launch(what);
-#else
-    set_error("%s: internal: no narrow kernel selected", what);
-    return TOAD_EINVAL;
-#endif
 }
 
-static int narrow_res_kmax() { return cfg().narrow_res_kmax; }
 static bool narrow_ok(int64_t M, int64_t N, int64_t K, int64_t ldc, const float *bias, const float *addend, void *ws) {
-    const bool wide_ok = addend && K <= narrow_res_kmax();       // residual GEMMs with a short reduction: epilogue-bound, see DESIGN 10
-    return narrow_enabled() && ws && (N <= 128 || wide_ok) && N % 4 == 0 && K % BK == 0 && ldc % 4 == 0 && M < (1ll << 31) &&
+    const bool wide_ok = addend && K <= kNarrowResKmax;       // residual GEMMs with a short reduction: epilogue-bound, see DESIGN 10
+    return ws && (N <= 128 || wide_ok) && N % 4 == 0 && K % BK == 0 && ldc % 4 == 0 && M < (1ll << 31) &&
            (!bias || aligned16(bias)) && (!addend || aligned16(addend));
 }
 
 // ---- h2 (fp16 two-piece) path ---------------------------------------------------------------------------------
-static int h2_enabled() { return cfg().h2; }
 // shapes the persistent h2 NT kernel serves (32-bit row offsets of A, whole 32-deep stages, 16-byte output rows)
 bool h2_nt_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc) {
-    return h2_enabled() && M >= 1 && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && lda % 4 == 0 && (uint64_t)M * lda * 4 < (1ull << 32);
+    return M >= 1 && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && lda % 4 == 0 && (uint64_t)M * lda * 4 < (1ull << 32);
 }
 size_t h2_planes_bytes(int64_t N, int64_t K) { return (size_t)((N + PB - 1) / PB) * PB * (size_t)K * 4; }   // two fp16 planes
 size_t h2_slab_bytes() { return (size_t)PB_GRID * PB * PB * sizeof(float); }
@@ -382,50 +317,8 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
     if (K % 4 != 0 || lda % 4 != 0 || ldb % 4 != 0) { set_error("%s: reduction dim %lld must be a multiple of 4", what, (long long)K); return TOAD_ESHAPE; }
     if (!aligned16(A) || !aligned16(B) || !aligned16(C)) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
     (void)cfg();
-    // Every shape the fp16 two-piece kernels take was routed to them by the caller (launch_nt_auto / ext_linear); what arrives here in the
-    // shipped library is the remainder (K % 32 != 0, no workspace, > 2^32-byte operands) for the generic exact-fp32 128x128 kernel.
-#ifdef TOAD_AB_KNOBS        // round 1's persistent arms (TOAD_GEMM_H2=0): split-bf16, or exact fp32 with TOAD_GEMM_SPLIT=0
-    const int use_big = cfg().big, use_split = cfg().split;
-    if (use_big && use_split && ws && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && (uint64_t)M * lda * 4 < (1ull << 32)) {
-        // B is given as B[n, k] = Bsrc[n * bsn + k * bsk]; split it into pre-swizzled bf16 planes behind the slabs
-        const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
-        unsigned short *planes = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(ws) + (size_t)PB_GRID * PB * PB * sizeof(float));
-        const int64_t pthreads = (int64_t)tiles_n * (K / BK) * PB * 4;
-        int pgrid = (int)((pthreads + 255) / 256);
-        if (pgrid > 4096) pgrid = 4096;
-        hipLaunchKernelGGL(split_planes_kernel, dim3(pgrid), dim3(256), 0, st, B, ldb, (int64_t)1, planes, (int)N, (int)K, tiles_n);
-        int rc = check_launch(what);
-        if (rc) return rc;
-        hipLaunchKernelGGL(gemm_nt_split_big_kernel, dim3(PB_GRID), dim3(512), SP_SMEM, st, A, lda, planes, C, ldc, (int)M,
-                           (int)N, (int)K, bias, es, addend, mask_src, (float *)ws, tiles_m, tiles_n);
-        rc = check_launch(what);
-        if (rc) return rc;
-        int max_rem = 0;                                   // fix-up grid: only as many tile rows as some XCD has remainder tiles
-        for (int x = 0; x < kNumXCD; ++x) { const int r = nt_plan(x, tiles_m, tiles_n, (int)(K / BK)).rem; if (r > max_rem) max_rem = r; }
-        if (max_rem > 0) {
-            hipLaunchKernelGGL(nt_fixup_kernel, dim3(64, max_rem, kNumXCD), dim3(256), 0, st, (const float *)ws, C,
-                               ldc, (int)M, (int)N, (int)K, bias, es, addend, mask_src, tiles_m, tiles_n);
-            rc = check_launch(what);
-        }
-        return rc;
-    }
-    if (use_big && ws && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && (uint64_t)M * lda * 4 < (1ull << 32) &&
-        (uint64_t)N * ldb * 4 < (1ull << 32)) {
-        const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
-        hipLaunchKernelGGL(gemm_nt_f32_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, A, lda, B, ldb, C, ldc, (int)M,
-                           (int)N, (int)K, bias, es, addend, mask_src, (float *)ws, tiles_m, tiles_n);
-        int rc = check_launch(what);
-        if (rc) return rc;
-        int max_rem = 0;                                   // fix-up grid: only as many tile rows as some XCD has remainder tiles
-        for (int x = 0; x < kNumXCD; ++x) { const int r = nt_plan(x, tiles_m, tiles_n, (int)(K / BK)).rem; if (r > max_rem) max_rem = r; }
-        if (max_rem > 0) {
-            hipLaunchKernelGGL(nt_fixup_kernel, dim3(64, max_rem, kNumXCD), dim3(256), 0, st, (const float *)ws, C,
-                               ldc, (int)M, (int)N, (int)K, bias, es, addend, mask_src, tiles_m, tiles_n);
-            rc = check_launch(what);
-        }
-        return rc;
-    }
-#endif
+    // Every shape the fp16 two-piece kernels take was routed to them by the caller (launch_nt_auto / ext_linear); what arrives here is
+    // the remainder (K % 32 != 0, no workspace, > 2^32-byte operands) for the generic exact-fp32 128x128 kernel.
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     const int grid = kNumXCD * ((tiles_m + kNumXCD - 1) / kNumXCD) * tiles_n;
     hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3(grid), dim3(256), NT_SMEM, st, A, lda, B, ldb, C, ldc, (int)M, (int)N,
@@ -469,7 +362,8 @@ using namespace toad;
 
 extern "C" size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K) {
     (void)M;
-    // one 256x256 fp32 slab per persistent block (64 MiB) + the three bf16 planes of the weight operand
+    // one 256x256 fp32 slab per persistent block (64 MiB) + room for the weight planes (6 bytes per element reserved since ABI 1; the
+    // two fp16 planes take 4)
     // K rounded up to an EVEN number of 32-deep stages: the streamed narrow kernels walk stages in pairs and their planes carry a zero
     // stage when the count is odd (at K = 32 that doubles the planes: 4 x 64 bytes per weight row > the 6 x 32 reserved before)
     const size_t tiles_n = (size_t)((N + PB - 1) / PB), kpad = (size_t)((K + 2 * BK - 1) / (2 * BK) * (2 * BK));
@@ -534,7 +428,7 @@ int toad::ext_linear(const float *X, const float *x_gmax, const float *W, const 
     if (int rc = check_ws(ws, ws_bytes, M, N, K, what)) return rc;
     EpiScalars es{act == TOAD_ACT_RELU, 1.f, make_drop(0.f, 0)};
     const bool narrow = narrow_ok(M, N, K, N, bias, residual, ws) && (uint64_t)M * K * 4 < (1ull << 32);
-    const bool big = !narrow && cfg().ext_h2 && h2_enabled() && ws && h2_nt_ok(M, N, K, K, N);
+    const bool big = !narrow && ws && h2_nt_ok(M, N, K, K, N);
     if ((narrow || big) && !x_gmax) {
         float *g = ext_scratch_scalar(ws, M, N, K);
         if (int rc = launch_gmax(X, M * K, g, st, what)) return rc;
@@ -643,7 +537,7 @@ extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const flo
                           H2Pool{pool_a_raw, pool_stats, pool_dM, pool_T}, dx_amax, nullptr, ws, (hipStream_t)stream, what);
 }
 
-static bool tn_big_ok(int64_t M, int64_t N, int64_t K) { return cfg().big && M >= 64 && N >= 4 && K >= 4; }
+static bool tn_big_ok(int64_t M, int64_t N, int64_t K) { return M >= 64 && N >= 4 && K >= 4; }
 
 extern "C" size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -658,7 +552,7 @@ extern "C" size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K) {
 int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, const float *x_amax, float *dW, float *db, int64_t M,
                         int64_t N, int64_t K, float beta, void *ws, hipStream_t st, const char *what, int x_mode, WgradDeferred *defer) {
     // x_mode: TOAD_X_F32 = fp32 [M][K]; TOAD_X_F16 = fp16 [M][K]; TOAD_X_PT = plane-tiled (gemm_pt.inc; x_amax = its per-row-tile abs-max)
-    if (x_mode != TOAD_X_F32 && !(tn_big_ok(M, N, K) && h2_enabled())) { set_error("%s: an fp16 / plane-tiled input operand needs the h2 wgrad kernels", what); return TOAD_ESHAPE; }
+    if (x_mode != TOAD_X_F32 && !tn_big_ok(M, N, K)) { set_error("%s: an fp16 / plane-tiled input operand needs the h2 wgrad kernels", what); return TOAD_ESHAPE; }
     if (x_mode == TOAD_X_PT && !x_amax) { set_error("%s: a plane-tiled operand comes with its abs-max array", what); return TOAD_EINVAL; }
     float *slab = (float *)ws;
     int nsplit;
@@ -669,7 +563,7 @@ int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, co
         const TnPlan q = tn_plan(M, N, K);
         nsplit = q.nsplit;
         float *cs = db ? slab + (size_t)nsplit * N * K : nullptr;
-        if (h2_enabled()) {
+        {
             h2 = true;
             scales = slab + (size_t)nsplit * (size_t)(N * K + N);
             float *amax_ws = scales + 16;
@@ -686,14 +580,6 @@ int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, co
                                    (int)M, (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
             }
         }
-#ifdef TOAD_AB_KNOBS        // round 1's arms (TOAD_GEMM_H2=0): split-bf16, or exact fp32 with TOAD_GEMM_SPLIT=0
-        else if (cfg().split)
-            hipLaunchKernelGGL(gemm_tn_split_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, X, K, slab, cs, (int)M,
-                               (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
-        else
-            hipLaunchKernelGGL(gemm_tn_f32_big_kernel, dim3(PB_GRID), dim3(512), PB_SMEM, st, dY, N, X, K, slab, cs, (int)M,
-                               (int)N, (int)K, q.rows_per_split, q.ti, q.tj, q.nsplit);
-#endif
         rc = check_launch(what);
     } else {
         const WgradPlan p = wgrad_plan(M, N, K);

@@ -269,86 +269,3 @@ def train_loop_dp(epoch: int, dp, loader: Iterable, batch_slides: int) -> Dict[s
         flush()
     s = (sums / max(n, 1)).cpu().tolist()
     return {"epoch": epoch, "slides": n, "cls_loss": s[0], "site_loss": s[1]}
-
-
-class EarlyStopping:
-    """Reference ``EarlyStopping`` (utils/core_utils_mtl_concat.py:44-85), same state machine and attribute names: stops when the watched
-    validation loss has not improved for ``patience`` consecutive validations AND ``epoch > stop_epoch``; every improvement (and the first
-    call) saves ``model.state_dict()`` to ``ckpt_name``. A tie counts as an improvement (``score < best_score`` is the only 'worse').
-    Pinned against the imported reference class on recorded loss sequences (oracle/pin_earlystop_against_reference.py,
-    tests/golden/toad_earlystop_golden.npz). (The reference initialises ``val_loss_min`` with ``np.Inf``, which NumPy 2 removed.)"""
-
-    def __init__(self, patience: int = 20, stop_epoch: int = 50, verbose: bool = False):
-        self.patience = patience
-        self.stop_epoch = stop_epoch
-        self.verbose = verbose
-        self.counter = 0
-        self.best_score = None
-        self.early_stop = False
-        self.val_loss_min = float("inf")
-
-    def __call__(self, epoch, val_loss, model, ckpt_name="checkpoint.pt"):
-        score = -val_loss
-        if self.best_score is None:
-            self.best_score = score
-            self.save_checkpoint(val_loss, model, ckpt_name)
-        elif score < self.best_score:
-            self.counter += 1
-            if self.verbose:
-                print(f"EarlyStopping counter: {self.counter} out of {self.patience}")
-            if self.counter >= self.patience and epoch > self.stop_epoch:
-                self.early_stop = True
-        else:
-            self.best_score = score
-            self.save_checkpoint(val_loss, model, ckpt_name)
-            self.counter = 0
-
-    def save_checkpoint(self, val_loss, model, ckpt_name):
-        if self.verbose:
-            print(f"Validation loss decreased ({self.val_loss_min:.6f} --> {val_loss:.6f}).  Saving model ...")
-        torch.save(model.state_dict(), ckpt_name)
-        self.val_loss_min = val_loss
-
-
-def train(loaders, cur: int, args, patience: int = 20, stop_epoch: int = 50):
-    """One fold of the reference's ``train(datasets, cur, args)`` (utils/core_utils_mtl_concat.py:87-187) on the HIP module: build the model
-    (``dropout=args.drop_out, n_classes=args.n_classes``), ``relocate()``, ``get_optim``, then per epoch ``train_loop`` and ``validate``;
-    with ``args.early_stopping`` the class validation loss drives ``EarlyStopping`` (checkpoint on every improvement, stop after ``patience``
-    non-improving validations once ``epoch > stop_epoch``; the reference hard-wires 20 / 50) and the BEST checkpoint
-    ``<results_dir>/s_<cur>_checkpoint.pt`` is loaded back before the final summaries; without it the last weights are saved there.
-    ``loaders`` = (train, val, test) iterables of ``(data, label, site, sex)`` batches - building them from the dataset classes is the
-    reference's data layer, out of scope here. Returns the reference's 9-tuple
-    ``(results_dict, cls_test_auc, cls_val_auc, cls_test_acc, cls_val_acc, site_test_auc, site_val_auc, site_test_acc, site_val_acc)``
-    plus the per-epoch log as a tenth element."""
-    import os
-    from .model_toad import TOAD_fc_mtl_concat
-    from .optim import get_optim
-    train_loader, val_loader, test_loader = loaders
-    os.makedirs(args.results_dir, exist_ok=True)
-    ckpt = os.path.join(args.results_dir, f"s_{cur}_checkpoint.pt")
-    loss_fn = nn.CrossEntropyLoss()
-    model = TOAD_fc_mtl_concat(dropout=args.drop_out, n_classes=args.n_classes)
-    model.relocate()
-    optimizer = get_optim(model, args)
-    stopper = EarlyStopping(patience=patience, stop_epoch=stop_epoch, verbose=getattr(args, "verbose", False)) if args.early_stopping else None
-    log = []
-    for epoch in range(args.max_epochs):
-        tr = train_loop(epoch, model, train_loader, optimizer, args.n_classes, loss_fn)
-        va = validate(model, val_loader, args.n_classes, loss_fn)
-        log.append({"epoch": epoch, "train_cls_loss": tr["cls_loss"], "val_cls_loss": va["cls_loss"], "val_cls_error": va["cls_error"]})
-        if stopper is not None:
-            stopper(epoch, va["cls_loss"], model, ckpt_name=ckpt)          # core_utils:358-364: the CLASS loss is the watched one
-            log[-1]["counter"] = stopper.counter
-            if stopper.early_stop:
-                break
-    if stopper is not None:
-        model.load_state_dict(torch.load(ckpt, map_location="cpu"))        # core_utils:148-149 (the flat parameter buffer keeps its address)
-    else:
-        torch.save(model.state_dict(), ckpt)
-    va = validate(model, val_loader, args.n_classes, loss_fn)
-    te = validate(model, test_loader, args.n_classes, loss_fn)
-    results = {"model": model, "test": te, "val": va}
-    nan = float("nan")
-    return (results, te.get("cls_auc", nan), va.get("cls_auc", nan), 1.0 - te["cls_error"], 1.0 - va["cls_error"],
-            te.get("site_auc", nan), va.get("site_auc", nan), 1.0 - te["site_error"], 1.0 - va["site_error"], log)
-
