@@ -8,9 +8,16 @@
     python bench.py --dropin [--patches N]                               # the reference's own call sequence, timed
 
 Headline (no --config). A "step" = one optimiser step of slide-sharded data parallel training: every rank runs
-forward + weighted CE + backward over its own synthetic 100,000-patch x 1024-d bag (fp32, already resident in HBM), ONE
-all-reduce of the 4.77 MB flat gradient over RCCL when N > 1, then Adam. value = slides/s over the whole job (N slides per
-step / max-over-ranks step time). Weak scaling. The JSON line also carries
+forward + weighted CE + backward over its own synthetic 100,000-patch x 1024-d bag - the RAW fp32 [N,1024] tensor, already
+resident in HBM, measured (abs-max pass) and split into the GEMMs' operand pieces INSIDE the step like every other activation -,
+ONE all-reduce of the 4.77 MB flat gradient over RCCL when N > 1, then Adam. value = slides/s over the whole job (N slides per
+step / max-over-ranks step time). Weak scaling. (The reference reloads every bag every epoch, datasets/dataset_mtl_concat.py:369-373 +
+utils/core_utils_mtl_concat.py:201-234, so nothing about a bag may be computed outside the timed region.) The JSON line also carries
+  prepared_pipelined  the ingest pipeline's form of the same loop (toad_amd/ingest.py BagPrefetcher(prepare=True)): while step i runs,
+                 bag i+1 - a raw fp32 device tensor - is converted on a side stream into the plane-tiled two-piece format the first
+                 Linear and its weight gradient take by LDS-DMA (toad_bag_prepare_f32); every byte-touching pass is inside the timed
+                 loop, value = steps / wall of the whole loop;
+  prepared_resident  the step alone on bags prepared BEFORE the timed region (round 3's headline; an ingest-format number, not credited);
   roofline       the fused gated-attention pooling forward (the kernel BASELINE.json's metric names): algorithmic bytes
                  4*[N*(2D+L+T)+T*D+T+T*L] per launch / mean launch time measured with HIP events on the launch stream inside
                  the timed steps, vs 8 TB/s HBM;
@@ -31,9 +38,13 @@ step / max-over-ranks step time). Weak scaling. The JSON line also carries
 
 --config 2   1 GPU, single 100k-patch bag, fused gated-attention pool FORWARD only; value = algorithmic GB/s; the oracle's
              gated_pool_fwd timed on the host cores beside it.
---config 3   1 GPU, full step (fwd + CE + bwd + Adam) on 10,000-patch bags; roofline_mfma + cpu_baseline (>= 10 repetitions).
+--config 3   1 GPU, full step (fwd + CE + bwd + Adam) on 10,000-patch bags, 8 per optimiser step through the ragged multi-slide call;
+             roofline (pool forward launches of the batch) + roofline_mfma + cpu_baseline (>= 10 repetitions).
 --config 4   64 slides x 50,000 patches per step, slide i on rank i mod G (shard_round_robin), one gradient all-reduce and one
-             Adam step per 64 slides: STRONG scaling over G = --gpus; runs at G = 1 too.
+             Adam step per 64 slides: STRONG scaling over G = --gpus; runs at G = 1 too; roofline + roofline_mfma + cpu_baseline
+             (one 50,000-patch slide on the host cores).
+Every N > 1 line carries per_rank: each rank's own step time (min / max / per rank), its pool-forward time and the all-reduce time it
+measured, so that a scaling run can attribute lost efficiency to load imbalance, the collective or clock spread between devices.
 """
 from __future__ import annotations
 
@@ -111,20 +122,25 @@ def measured_pool_traffic(n: int):
     return None
 
 
+PROBE_BUDGET_S = 10.0      # wall-clock cap of the thread-count probe (the driver's lease should be GPU time, not host probing)
+
+
 def _probe_threads(once, budget_s: float, min_reps: int):
     """PyTorch-CPU does not scale to every hardware thread of a big host (256 threads run ~7x slower than 64 here), and the
-    best count depends on the problem size: probe {4, 8, 16, 32, 64, physical} with one repetition each (after a warm-up),
-    then time the FASTEST (median of >= min_reps) - the baseline is the best this CPU path can do on this box."""
+    best count depends on the problem size: probe 32 threads first (the winner on every box measured so far), then 16 / 64 /
+    physical while the probe has spent less than PROBE_BUDGET_S, one repetition each after a warm-up; then time the FASTEST
+    (median of >= min_reps) - the baseline is the best this CPU path can do on this box within a bounded sample."""
     logical = os.cpu_count() or 1
     phys = min(_physical_cores(), logical)
-    cands = sorted({t for t in (4, 8, 16, 32, 64, phys) if t <= max(phys, 4)})
+    cands = [t for t in (32, 16, 64, phys, 8) if t <= max(phys, 4)]
+    cands = list(dict.fromkeys(cands)) or [max(1, phys)]
     probe = {}
     t_start = time.perf_counter()
     for th in cands:
         torch.set_num_threads(th)
         once()                                   # warm-up at this thread count
         probe[th] = once()
-        if time.perf_counter() - t_start > budget_s * 0.6:
+        if time.perf_counter() - t_start > min(PROBE_BUDGET_S, budget_s * 0.5):
             break
     best = min(probe, key=probe.get)
     torch.set_num_threads(best)
@@ -184,7 +200,7 @@ def cpu_baseline_pool(n_patches: int, budget_s: float = 20.0):
 
 
 BAG_DTYPE = torch.float32          # --bag-dtype fp16: bags stored in half precision (a side experiment, never the headline)
-BAG_PREPARED = True                # --bag-format prepared: the ingest format (toad_bag_prepare_f32); fp32: the raw tensor
+BAG_PREPARED = False               # --bag-format prepared: bags converted to the ingest format BEFORE the timed region (not the headline)
 
 
 def make_slide(idx: int, n: int, dev, prepared=None):
@@ -215,11 +231,12 @@ def time_prepare(n: int, dev, reps: int = 5):
     return round(t[len(t) // 2] * 1e3, 1)
 
 
-def gemm_roofline(timing, n_patches_per_set):
-    gemm_ms = sum(timing[k][1] for k in ("gemm_fwd", "gemm_dgrad", "gemm_wgrad"))
-    sets = timing["gemm_fwd"][0] // 3                                   # 3 forward GEMMs per slide
-    gemm_t = gemm_ms / sets * 1e-3
-    tf = GEMM_FLOP_PER_PATCH * n_patches_per_set / gemm_t
+def gemm_roofline(timing, rows_total):
+    """All GEMM calls of the instrumented steps: algorithmic 6,029,312 FLOP per patch row x the rows those steps processed / the
+    summed HIP-event time of the calls (per-slide calls: 8 per slide; the ragged multi-slide call: 8 per batch)."""
+    gemm_t = sum(timing[k][1] for k in ("gemm_fwd", "gemm_dgrad", "gemm_wgrad")) * 1e-3
+    calls = timing["gemm_fwd"][0] // 3                                  # library calls (3 forward GEMMs each)
+    tf = GEMM_FLOP_PER_PATCH * rows_total / gemm_t
     return {"bound": "mfma",
             "kernel": "gemm_nt_h2_big_kernel x5 (+split_planes_h2, nt_fixup_h2) + gemm_tn_h2_big_kernel x3 (+slab_reduce_h2)",
             "achieved": round(tf / 1e12, 2), "peak": round(MFMA_EQ_PEAK / 1e12, 1),
@@ -231,7 +248,48 @@ def gemm_roofline(timing, n_patches_per_set):
             # tools/ubench/mfma_power (profiles/r02av): the matrix pipe ALONE, on random fp16 operands, sustains 1735 of the nominal 2500
             # TFLOP/s (1.7 GHz; the nominal rate needs zeros) - context for `frac`, which stays against the nominal peak
             "frac_of_measured_mfma_only_rate_578": round(tf / (1735e12 / SPLIT_TERMS), 4),
-            "algorithmic_flops": GEMM_FLOP_PER_PATCH * n_patches_per_set, "us_per_slide": round(gemm_t * 1e6, 1)}
+            "algorithmic_flops": GEMM_FLOP_PER_PATCH * rows_total, "rows": rows_total, "library_calls": calls,
+            "us_per_call": round(gemm_t / max(calls, 1) * 1e6, 1)}
+
+
+def time_prepared_pipelined(dp, raw_slides, global_slides: int, steps: int, warmup: int, dev, sync):
+    """The ingest pipeline's loop with every pass inside the timed region (toad_amd/ingest.py, BagPrefetcher(prepare=True)): while step i
+    runs on the launch stream, bag i+1 - a raw fp32 [N,1024] device tensor, as the host-to-device copy leaves it - is measured and
+    converted into the plane-tiled two-piece format on a SIDE stream (toad_bag_prepare_f32: abs-max pass + split pass, 820 MB read +
+    410 MB written per 100k-patch bag), into one of two alternating buffers. Events order it: a step waits for its bag's conversion,
+    a conversion waits for the step that last read its buffer. Returns seconds per step (wall of the whole loop / steps)."""
+    from toad_amd import ops
+    main = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(device=dev)
+    nraw = len(raw_slides)
+    bufs = [ops.prepare_bag(raw_slides[b % nraw][0][0]) for b in range(2)]          # the two ingest buffers (contents overwritten below)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    free = [torch.cuda.Event() for _ in range(2)]
+    torch.cuda.synchronize()
+
+    def convert(i):                                   # bag i -> buffer i % 2, on the side stream
+        with torch.cuda.stream(side):
+            side.wait_event(free[i % 2])
+            ops.prepare_bag(raw_slides[i % nraw][0][0], out=bufs[i % 2])
+            ready[i % 2].record(side)
+
+    def run(k):
+        for b in range(2):
+            free[b].record(main)
+        convert(0)
+        for i in range(k):
+            convert(i + 1)                            # overlaps step i
+            main.wait_event(ready[i % 2])
+            _, sex, label, site = raw_slides[i % nraw][0]
+            dp.step([(bufs[i % 2], sex, label, site)], global_slides)
+            free[i % 2].record(main)
+
+    run(max(warmup, 2))
+    sync()
+    t0 = time.perf_counter()
+    run(steps)
+    sync()
+    return (time.perf_counter() - t0) / steps
 
 
 def time_dropin(n: int, steps: int, warmup: int, dev, host_reads: bool):
@@ -364,9 +422,11 @@ def main():
     ap.add_argument("--bag-dtype", choices=["fp32", "fp16"], default="fp32",
                     help="fp16: feature bags stored in half precision (toad_mil_step_x16_f32: two MFMA terms in the first layer, no abs-max pass); "
                          "reported under its own metric name, BASELINE's configurations are fp32")
-    ap.add_argument("--bag-format", choices=["prepared", "fp32"], default="prepared",
-                    help="prepared (default): bags resident in the ingest format of toad_bag_prepare_f32 (two fp16 pieces per fp32 element, "
-                         "plane-tiled; made once per slide); fp32: the raw [N,1024] fp32 tensor, re-measured and re-split by every step")
+    ap.add_argument("--bag-format", choices=["fp32", "prepared"], default="fp32",
+                    help="fp32 (default, the headline): the raw [N,1024] fp32 tensor, measured and split inside every step; prepared: bags "
+                         "converted to the ingest format of toad_bag_prepare_f32 BEFORE the timed region (an ingest-format experiment, "
+                         "reported under its own metric name)")
+    ap.add_argument("--no-prepared-legs", action="store_true", help="headline run without the prepared_pipelined / prepared_resident legs")
     ap.add_argument("--patches", type=int, default=0, help="patches per slide (default: 100,000; config 3: 10,000; config 4: 50,000)")
     ap.add_argument("--slides-per-rank", type=int, default=0,
                     help="slides per rank per optimiser step (default 1; config 3: 8). Several small fp32 slides of a rank go through ONE "
@@ -404,7 +464,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # a process group exists whenever the ranks were started by torch.distributed.run - also at world 1, where the gradient all-reduce
+    # is then issued every step like at N > 1 (the collective path on one GPU: tests/test_gpu_launch_bench.py); the plain
+    # `python bench.py` run has none and skips the collective inside the step
+    under_torchrun = launch.launched_by_torchrun()
+    if world > 1 or under_torchrun:
         launch.init_process_group(args.backend, device=dev if args.backend == "nccl" else None)
 
     if args.config == 2:
@@ -427,7 +491,7 @@ def main():
     model = TOAD_fc_mtl_concat(dropout=False, n_classes=C)
     model.relocate()
     model.train()
-    dp = SlideShardedDP(model, {"lr": 1e-4, "weight_decay": 1e-5})      # get_optim defaults (main_mtl_concat.py:93-96), HIP flat Adam
+    dp = SlideShardedDP(model, {"lr": 1e-4, "weight_decay": 1e-5}, always_reduce=under_torchrun)      # get_optim defaults (main_mtl_concat.py:93-96), HIP flat Adam
 
     if args.config == 4:
         n = args.patches or 50_000
@@ -446,22 +510,27 @@ def main():
         global_slides = spr * world
         scaling = "weak"
     patches_per_rank_step = n * len(slides[0])
+    prepared = BAG_PREPARED and args.bag_dtype == "fp32" and n >= 64
+    batched = len(slides[0]) > 1 and n <= SlideShardedDP.BATCH_MAX_PATCHES and args.bag_dtype == "fp32" and not prepared
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         dp.step(slides[i % nbags], global_slides)
     # Timed region: only the dominant HBM-bound kernel (the fused pool forward) is bracketed by HIP events (2 pre-created events
-    # per slide). Bracketing all eight GEMM calls as well costs 18 event packets per slide (~0.1 ms of stream time: 4 % of a
+    # per library call). Bracketing all eight GEMM calls as well costs 18 event packets per call (~0.1 ms of stream time: 4 % of a
     # 100k-patch step, 2x of a 256-patch step), so the GEMM breakdown is measured in its own instrumented loop right after.
     ops.enable_timing(True, level=1, prealloc=2 * args.steps * len(slides[0]))
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         losses = dp.step(slides[i % nbags], global_slides)
+    torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0               # this rank's own time for its K steps (before the closing barrier)
     sync()
     elapsed = time.perf_counter() - t0
     timing = ops.collect_timing()
@@ -493,11 +562,25 @@ def main():
             if flag.item() > 0 or sus_steps >= 200000:
                 break
 
+    allreduce = time_allreduce(dp, dev, world, args.backend)
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed, sus_t], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, sus_t = float(t[0].item()), float(t[1].item())
-    allreduce = time_allreduce(dp, dev, world, args.backend)
+        # what a scaling run needs to attribute lost efficiency: every rank's own step time (load imbalance / clock spread between
+        # devices), its pool-forward launch time (a bandwidth-bound probe of that device) and the all-reduce time it measured
+        pool_us = (timing["pool_fwd"][1] / timing["pool_fwd"][0] * 1e3) if "pool_fwd" in timing else float("nan")
+        mine_t = torch.tensor([local_elapsed / args.steps * 1e3, pool_us, float(allreduce.get("us", float("nan"))), float(patches_per_rank_step)],
+                              device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(allr, mine_t)
+        rows = [[float(v) for v in r.tolist()] for r in allr]
+        per_rank = {"step_ms": [round(r[0], 4) for r in rows], "step_ms_min": round(min(r[0] for r in rows), 4),
+                    "step_ms_max": round(max(r[0] for r in rows), 4), "pool_fwd_us": [round(r[1], 2) for r in rows],
+                    "allreduce_us": [round(r[2], 2) for r in rows], "patches_per_step": [int(r[3]) for r in rows],
+                    "what": "step_ms = a rank's own wall time per step up to its local synchronize (before the closing barrier); ms_per_step of "
+                            "the line is the max over ranks including the barrier"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -508,6 +591,8 @@ def main():
             metric = f"slides/sec fwd+bwd, {n}-patch x 1024-d bags"
         if args.bag_dtype == "fp16":
             metric += " STORED AS fp16 (not a BASELINE configuration)"
+        if prepared:
+            metric += " PREPARED BEFORE THE TIMED REGION (ingest-format experiment, not the headline)"
         out = {
             "metric": metric,
             "value": round(value, 3), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -516,56 +601,69 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"TOAD_fc_mtl_concat(big, n_classes=18) fwd + 0.75/0.25 CE + bwd + Adam on "
                                    f"{len(slides[0])} x {n}-patch x 1024-d N(0,1) fp32 bag(s) per GPU per step, bags resident in HBM"
-                                   + (" in the ingest format (toad_bag_prepare_f32, once per slide: both fp16 pieces of every fp32 element, plane-tiled, 4 B/element)"
-                                      if (BAG_PREPARED and args.bag_dtype == "fp32" and n >= 64) else " as raw tensors")
+                                   + (" in the ingest format (toad_bag_prepare_f32 BEFORE the timed region: both fp16 pieces of every fp32 element, plane-tiled, 4 B/element)"
+                                      if prepared else " as raw fp32 tensors; the abs-max pass over the bag and its split into the GEMM operand pieces run inside every timed step")
                                    + (f"; 64 slides per optimiser step dealt round robin over {world} rank(s)" if args.config == 4 else ""),
                        "arithmetic": "fp32 storage/accumulation; GEMM operands as two fp16 pieces (x*s = h+m, power-of-two scales), 3 MFMA terms = "
                                      "fp32-equivalent, verified vs fp64 (tools/split_emulation.py, tests/test_gpu_h2.py)",
                        "patches_per_slide": n, "slides_per_step": global_slides,
                        "batching": ("one ragged multi-slide call per rank and step (toad_mil_multi_step_f32: trunk / attention GEMMs once over the "
                                     "concatenated bags, pooling + heads + loss per slide; the concatenation is inside the timed step)"
-                                    if (len(slides[0]) > 1 and n <= SlideShardedDP.BATCH_MAX_PATCHES and args.bag_dtype == "fp32") else "one library call per slide"),
-                       "parallelism": f"slide-sharded dp{world}, one {4 * model.flat_parameters().numel() / 1e6:.2f} MB grad all-reduce/step"},
+                                    if batched else "one library call per slide"),
+                       "parallelism": f"slide-sharded dp{world}, one {4 * model.flat_parameters().numel() / 1e6:.2f} MB grad all-reduce/step"
+                                      + (" (issued at world 1 too: started by torch.distributed.run)" if under_torchrun and world == 1 else "")},
         }
         if "pool_fwd" in timing:
             calls, tot_ms = timing["pool_fwd"]
             pool_t = tot_ms / calls * 1e-3
-            pool_bw = pool_fwd_bytes(n) / pool_t
-            out["roofline"] = {"bound": "hbm", "kernel": "gated_pool_fwd_kernel<2,3,4,true> + gated_pool_combine_kernel",
+            calls_per_step = calls / args.steps                          # per-slide calls: slides per rank; ragged batch call: 1
+            slides_per_call = len(slides[0]) / calls_per_step
+            pool_bytes = pool_fwd_bytes(n) * slides_per_call             # one launch pools every slide of the call (blockIdx.y = slide)
+            pool_bw = pool_bytes / pool_t
+            out["roofline"] = {"bound": "hbm", "kernel": "gated_pool_fwd_kernel<2,3,4,true> + gated_pool_combine_kernel"
+                                                         + (f" (batched launch: {slides_per_call:g} slides, blockIdx.y = slide)" if slides_per_call > 1 else ""),
                                "achieved": round(pool_bw / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": round(pool_bw / HBM_PEAK, 4), "traffic": measured_pool_traffic(n),
-                               "algorithmic_bytes": pool_fwd_bytes(n), "us_per_launch": round(pool_t * 1e6, 2)}
-            out["roofline_mfma"] = gemm_roofline(timing_gemm, n)
-            out["roofline_mfma"]["measured_in"] = f"{k_instr} instrumented steps right after the timed region (18 events per slide)"
-            out["op_us_per_slide"] = {k: round(v[1] / timing_gemm["pool_fwd"][0] * 1e3, 1) for k, v in timing_gemm.items()}
+                               "frac": round(pool_bw / HBM_PEAK, 4), "traffic": measured_pool_traffic(n) if slides_per_call == 1 else None,
+                               "algorithmic_bytes": int(pool_bytes), "us_per_launch": round(pool_t * 1e6, 2)}
+            out["roofline_mfma"] = gemm_roofline(timing_gemm, k_instr * patches_per_rank_step)
+            out["roofline_mfma"]["measured_in"] = f"{k_instr} instrumented steps right after the timed region (18 events per library call)"
+            out["op_us_per_slide"] = {k: round(v[1] / (k_instr * len(slides[0])) * 1e3, 1) for k, v in timing_gemm.items()}
         if sus_steps:
             out["sustained"] = {"value": round(global_slides * sus_steps / sus_t, 3), "unit": "slides/s", "steps": sus_steps,
                                 "seconds": round(sus_t, 3), "ms_per_step": round(sus_t / sus_steps * 1e3, 3)}
         out["allreduce"] = allreduce
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         out["last_loss"] = round(last_loss, 5)
-        if world == 1 and args.config in (0, 3) and BAG_PREPARED and args.bag_dtype == "fp32" and n >= 64:
-            # the same K steps on RAW fp32 bags (abs-max pass + in-kernel splitting of the bag every step), and the one-off cost of preparing a bag
-            raw = [[make_slide((rank * spr + s_) * nbags + b, n, dev, prepared=False) for s_ in range(spr)] for b in range(nbags)]
+        if world == 1 and args.config == 0 and not prepared and args.bag_dtype == "fp32" and n >= 64 and ops.x16_ok(n) and not args.no_prepared_legs:
+            # (b) the ingest pipeline's loop: conversion of bag i+1 on a side stream while step i runs, everything inside the timed loop
+            sec = time_prepared_pipelined(dp, slides, global_slides, args.steps, args.warmup, dev, sync)
+            out["prepared_pipelined"] = {"value": round(global_slides / sec, 3), "unit": "slides/s", "ms_per_step": round(sec * 1e3, 3), "steps": args.steps,
+                                         "what": "step i on a plane-tiled two-piece bag while toad_bag_prepare_f32 converts raw fp32 bag i+1 on a side stream "
+                                                 "(two alternating buffers, event-ordered); value = steps / wall of the whole loop, conversions included"}
+            # (c) round 3's headline: bags converted before the timed region (an ingest-format number; not credited)
+            pre = [[(ops.prepare_bag(sl[0]),) + tuple(sl[1:]) for sl in group] for group in slides]
             for i in range(3):
-                dp.step(raw[i % nbags], global_slides)
+                dp.step(pre[i % nbags], global_slides)
             sync(); t2 = time.perf_counter()
             for i in range(args.steps):
-                dp.step(raw[i % nbags], global_slides)
-            sync(); raw_ms = (time.perf_counter() - t2) / args.steps * 1e3
-            del raw
-            out["fp32_bag"] = {"value": round(global_slides * 1e3 / raw_ms, 3), "unit": "slides/s", "ms_per_step": round(raw_ms, 3), "steps": args.steps,
-                               "what": "same step on raw fp32 [N,1024] bags (toad_mil_step_f32: per-step abs-max pass + in-kernel splitting of the bag)",
-                               "prepare_us_per_bag": time_prepare(n, dev)}
+                dp.step(pre[i % nbags], global_slides)
+            sync(); pre_ms = (time.perf_counter() - t2) / args.steps * 1e3
+            del pre
+            out["prepared_resident"] = {"value": round(global_slides * 1e3 / pre_ms, 3), "unit": "slides/s", "ms_per_step": round(pre_ms, 3), "steps": args.steps,
+                                        "what": "the step alone on bags converted BEFORE the timed region (toad_mil_step_xp_f32); the conversion it leaves out costs",
+                                        "prepare_us_per_bag": time_prepare(n, dev)}
         if world == 1 and args.config in (0, 3) and not args.no_dropin:
             k = max(args.steps, 10)
             ms = time_dropin(n, k, 3, dev, host_reads=False)
             ms_h = time_dropin(n, k, 3, dev, host_reads=True)
             out["dropin"] = {"ms_per_step": round(ms, 4), "value": round(1e3 / ms, 2), "unit": "slides/s", "steps": k,
-                             "ms_per_step_with_host_reads": round(ms_h, 4), "vs_fused_step": round(ms / ms_per_step, 3),
+                             "ms_per_step_with_host_reads": round(ms_h, 4), "vs_fused_step": round(ms / (ms_per_step / len(slides[0])), 3),
                              "what": "model(data, sex) + nn.CrossEntropyLoss x2 + loss.backward() + torch.optim.Adam(model.parameters()).step() + "
                                      "zero_grad() (utils/core_utils_mtl_concat.py:206-234); host reads = the loop's .item() / int() per slide"}
-        if world == 1 and not args.no_cpu_baseline and args.config in (0, 3):
-            out["cpu_baseline"] = cpu_baseline_step(n, budget_s=30.0 if n >= 50_000 else 15.0, min_reps=3 if n >= 50_000 else 10)
+        if world == 1 and not args.no_cpu_baseline:
+            # the CPU port on ONE slide of this configuration's size (config 4: one 50,000-patch slide; the 64-slide step is 64 of them)
+            out["cpu_baseline"] = cpu_baseline_step(n, budget_s=20.0 if n >= 50_000 else 15.0, min_reps=3 if n >= 50_000 else 10)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
     if dist.is_initialized():                                 # tear the communicator down first: the JSON line stays the LAST line on stdout
         dist.barrier()

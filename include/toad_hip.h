@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOAD_ABI_VERSION 9
+#define TOAD_ABI_VERSION 10
 
 enum { TOAD_OK = 0, TOAD_EINVAL = -1, TOAD_ESHAPE = -2, TOAD_EWORKSPACE = -3, TOAD_EALIGN = -4 };
 enum { TOAD_ACT_NONE = 0, TOAD_ACT_RELU = 1 };
@@ -372,7 +372,7 @@ int toad_mil_step_xp_f32(const float *const *params, float *const *grads, float 
                          float *loss_out, float *logits_out, float *site_logits_out,
                          void *ws, size_t ws_bytes, void **events, void *stream);
 
-/* ---- ragged multi-slide training step (ABI 9) -------------------------------------------------------------------------------
+/* ---- ragged multi-slide training step (ABI 9; `events` since ABI 10) -----------------------------------------------------------
  * One call = forward + weighted CE + backward for a BATCH of B slides whose bags lie concatenated in Xcat [sum N_b, 1024]
  * (reference loop body: utils/core_utils_mtl_concat.py:200-234, one slide per iteration; data-parallel semantics: one optimiser
  * step per batch, toad_amd/dp.py). The five trunk / attention GEMMs of the forward and of the backward run ONCE over all rows;
@@ -380,12 +380,15 @@ int toad_mil_step_xp_f32(const float *const *params, float *const *grads, float 
  *   offsets : HOST array [B+1] of row offsets (offsets[0] = 0, strictly increasing); sex / label / site : DEVICE arrays [B];
  *   loss_out [B][3] (weighted loss, cls CE, site CE); logits_out [B][C], site_logits_out [B][2] (either may be NULL);
  *   ws >= toad_mil_multi_ws_bytes(sum N_b, B, C, D). Agrees with B calls of toad_mil_step_f32 to fp32 round-off (operand scales
- *   are taken per 256-row block of the concatenation), not bitwise. */
+ *   are taken per 256-row block of the concatenation), not bitwise.
+ *   events : NULL, or 18 hipEvent_t laid out as for toad_mil_step_f32 ([0,1] bracket the batched pool forward + merge, [2+2i, 3+2i] GEMM
+ *   call i of fwd1, fwd2, fwd_ab, wgrad_ab, dgrad_ab, wgrad_2, dgrad_2, wgrad_1) - bench.py's roofline figures of the batched configurations. */
 size_t toad_mil_multi_ws_bytes(int64_t Ntot, int B, int C, int D);
 int toad_mil_multi_step_f32(const float *const *params, float *const *grads, float beta, const float *Xcat,
                             const int64_t *offsets, int B, const float *sex, const int64_t *label, const int64_t *site,
                             float w_cls, float w_site, int C, int D, float drop_p, uint64_t seed,
-                            float *loss_out, float *logits_out, float *site_logits_out, void *ws, size_t ws_bytes, void *stream);
+                            float *loss_out, float *logits_out, float *site_logits_out, void *ws, size_t ws_bytes, void **events,
+                            void *stream);
 
 #ifdef __cplusplus
 }

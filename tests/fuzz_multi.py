@@ -1,7 +1,9 @@
 """Random ragged batches through toad_mil_multi_step_f32 against the sum of the oracle's per-slide fp64 gradients (the third check of
 __graft_entry__.smoke() over many batch compositions). Not collected by pytest: `python tests/fuzz_multi.py [cases] [seed]` on a GPU box.
-Tolerance 1e-3 of each gradient's scale (a ReLU-boundary flip may move a trunk gradient by one patch's contribution) for the trunk, 2e-5 + noise
-for the mask-free head / attention-c gradients; per-slide losses and logits to 1e-4."""
+Checked per case: all 14 parameter gradients (the stacked attention_a / attention_b weights and biases through the `wab` / `bab` slots, every
+bias slot) - 1e-3 of each gradient's scale for the trunk / attention weights (a ReLU-boundary flip may move them by one patch's contribution;
+then the rank-one test decides), 2e-5 .. 1e-4 for the mask-free head / attention-c gradients - and the per-slide losses and logits the call
+returns, to 1e-4 against the oracle's fp64 values."""
 import os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,8 +24,11 @@ for k, v in params.items():
 model = TOAD_fc_mtl_concat(n_classes=c); model.load_state_dict(params); model.relocate()
 w = {k: v.detach() for k, v in model._weights().items()}
 p64 = {k: v.double() for k, v in params.items()}
-KEYS = (("wcls", "classifier.weight", 2e-5), ("wsite", "site_classifier.weight", 2e-5), ("wc", "attention_net.4.attention_c.weight", 1e-4),
-        ("w2", "attention_net.2.weight", 1e-3), ("w1", "attention_net.0.weight", 1e-3), ("wab", None, 1e-3))
+A, B_ = "attention_net.4.attention_a.0.", "attention_net.4.attention_b.0."
+KEYS = (("wcls", "classifier.weight", 2e-5), ("bcls", "classifier.bias", 2e-5), ("wsite", "site_classifier.weight", 2e-5),
+        ("bsite", "site_classifier.bias", 2e-5), ("wc", "attention_net.4.attention_c.weight", 1e-4), ("bc", "attention_net.4.attention_c.bias", 1e-4),
+        ("w2", "attention_net.2.weight", 1e-3), ("b2", "attention_net.2.bias", 1e-3), ("w1", "attention_net.0.weight", 1e-3),
+        ("b1", "attention_net.0.bias", 1e-3), ("wab", (A + "weight", B_ + "weight"), 1e-3), ("bab", (A + "bias", B_ + "bias"), 1e-3))
 nfail = 0
 for i in range(cases):
     B = rng.randint(1, 12)
@@ -32,25 +37,41 @@ for i in range(cases):
     labels = torch.tensor([rng.randrange(c) for _ in range(B)]); sites = torch.tensor([rng.randint(0, 1) for _ in range(B)])
     sexes = torch.tensor([float(rng.randint(0, 1)) for _ in range(B)])
     g = {k: torch.zeros_like(w[k]) for k in ops.STEP_SLOTS}
-    out = ops.mil_multi_step(w, g, 0.0, [b.to(dev) for b in bags], sexes.to(dev), labels.to(dev), sites.to(dev), 0.75 / B, 0.25 / B)
+    out = ops.mil_multi_step(w, g, 0.0, [b.to(dev) for b in bags], sexes.to(dev), labels.to(dev), sites.to(dev), 0.75 / B, 0.25 / B, want_logits=True)
     tot = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in params.items()}
     ok, msgs = True, []
     for j, (b, lb, st, sx) in enumerate(zip(bags, labels, sites, sexes)):
         o_out, o_loss, gd = orc.fwd_bwd(p64, b.double(), sx.reshape(1).double(), lb.reshape(1), st.reshape(1))
         for k in tot:
             tot[k] += gd[k] / B
-    for slot, key, tol in KEYS:
-        if key is None:
-            continue
-        sc = tot[key].abs().max().item()
-        err = (g[slot].cpu().double() - tot[key]).abs().max().item()
+        # per-slide results of the call: loss [B, 3] = (weighted loss / B, class CE, site CE), logits [B, C], site logits [B, 2]
+        cls_ce = torch.nn.functional.cross_entropy(o_out["logits"], lb.reshape(1)).item()
+        site_ce = torch.nn.functional.cross_entropy(o_out["site_logits"], st.reshape(1)).item()
+        got = out[0][j].cpu().double()
+        e_loss = max(abs(got[0].item() - float(o_loss) / B), abs(got[1].item() - cls_ce), abs(got[2].item() - site_ce))
+        e_log = max((out[1][j].cpu().double() - o_out["logits"][0]).abs().max().item(), (out[2][j].cpu().double() - o_out["site_logits"][0]).abs().max().item())
+        if e_loss > 1e-4 or e_log > 1e-4:
+            ok = False; msgs.append(f"slide {j}: loss err {e_loss:.2e} logits err {e_log:.2e}")
+    flips = {}
+    for slot, key, tol in sorted(KEYS, key=lambda t: t[0].startswith("b")):          # weights first: their flip counts license the bias slots
+        ref = torch.cat([tot[key[0]], tot[key[1]]]) if isinstance(key, tuple) else tot[key]
+        sc = ref.abs().max().item()
+        err = (g[slot].cpu().double() - ref).abs().max().item()
         if err > tol * sc + 1e-12:
-            # a trunk gradient may differ by a few LEGITIMATE ReLU-boundary flips: rank-one terms of one patch's size (tests/helpers.py)
+            # a trunk gradient may differ by a few LEGITIMATE ReLU-boundary flips: rank-one terms of one patch's size (tests/helpers.py);
+            # the bias of a layer then moves by that patch's dZ element, allowed only when the layer's weight gradient showed the flip
             try:
                 if tol < 1e-3:
                     raise AssertionError("mask-free gradient")
-                nflip = helpers.assert_grad_close_or_few_flips(g[slot], tot[key], 1e-4, sc, what=slot, max_flips=8, flip_size=3e-2)
-                msgs.append(f"{slot}: {nflip} flip(s)")
+                if ref.dim() < 2:
+                    nf = flips.get("w" + slot[1:], 0)
+                    if nf == 0 or err > 3e-2 * sc * nf:
+                        raise AssertionError(f"bias gradient off with {nf} flip(s) in its layer")
+                    msgs.append(f"{slot}: moved by its layer's flip(s)")
+                else:
+                    nflip = helpers.assert_grad_close_or_few_flips(g[slot], ref, 1e-4, sc, what=slot, max_flips=8, flip_size=3e-2)
+                    flips[slot] = nflip
+                    msgs.append(f"{slot}: {nflip} flip(s)")
             except AssertionError as ex:
                 ok = False; msgs.append(f"{slot} err {err:.2e} scale {sc:.2e} ({str(ex)[:60]})")
     nfail += 0 if ok else 1

@@ -31,7 +31,7 @@ def oracle_slide_grad(model, grads, slide, beta, scale):
     return torch.stack([loss * scale, loss, loss])
 
 
-def worker(rank, world, port, ret):
+def worker(rank, world, port, ret, n_slides=N_SLIDES):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -41,8 +41,9 @@ def worker(rank, world, port, ret):
     model = TOAD_fc_mtl_concat(n_classes=18)
     dp = SlideShardedDP(model, lambda ps: torch.optim.SGD(ps, lr=0.1), slide_grad_fn=oracle_slide_grad)
     start = model.flat_parameters().clone()
-    mine = shard_round_robin(N_SLIDES, rank, world)
-    dp.step([make_slide(i) for i in mine], N_SLIDES)
+    mine = shard_round_robin(n_slides, rank, world)
+    dp.flat_grad.fill_(7.0)                             # stale contents: a rank without slides must still contribute ZERO
+    dp.step([make_slide(i) for i in mine], n_slides)
     ret[rank] = (start, dp.flat_grad.clone(), model.flat_parameters().clone(), mine,
                  {k: v.clone() for k, v in model.state_dict().items()})
     dist.barrier()
@@ -73,6 +74,29 @@ def test_dp_world2_gradient_is_mean_of_slide_gradients():
     for k in params:
         new = sd0[k]
         assert torch.allclose(new, params[k] - 0.1 * mean[k], atol=1e-6, rtol=1e-5), k
+
+
+@pytest.mark.timeout(300)
+def test_dp_rank_without_slides_contributes_zero():
+    """global_slides < world (the tail of an epoch, or BASELINE config 4 on more ranks than slides): the rank that holds no slide
+    zeroes its bucket, still joins the ONE all-reduce and takes the same optimiser step - nobody hangs, every replica stays identical."""
+    world, n_slides, port = 3, 2, 31500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(worker, args=(world, port, ret, n_slides), nprocs=world, join=True)
+    assert [ret[r][3] for r in range(world)] == [[0], [1], []]
+    for r in (1, 2):
+        assert torch.equal(ret[0][1], ret[r][1]) and torch.equal(ret[0][2], ret[r][2]), r
+    torch.manual_seed(100)
+    from toad_amd import TOAD_fc_mtl_concat
+    params = {k: v.detach().clone() for k, v in TOAD_fc_mtl_concat(n_classes=18).state_dict().items()}
+    mean = {k: torch.zeros_like(v) for k, v in params.items()}
+    for i in range(n_slides):
+        _, _, g = orc.fwd_bwd(params, *make_slide(i))
+        for k in mean:
+            mean[k] += g[k] / n_slides
+    for k in params:
+        assert torch.allclose(ret[2][4][k], params[k] - 0.1 * mean[k], atol=1e-6, rtol=1e-5), k
 
 
 def test_partitioners():

@@ -1,0 +1,39 @@
+"""GPU: bench.py started the way the driver starts it for N > 1 - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (toad_amd/launch.py builds that command line) - with backend "nccl" (RCCL)
+on the one GPU a test box has. A process group then exists at world 1 and the step issues its gradient all-reduce through RCCL exactly
+as it does at N = 8 (SlideShardedDP(always_reduce=True)); BASELINE config 4's strong-scaling line must come back as ONE JSON line.
+What this cannot show is the xGMI transfer between devices; everything else of `bench.py --config 4 --gpus 8` runs here.
+Reference being replaced: the intra-bag nn.DataParallel of models/model_toad.py:79-81 (not reproduced)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_config4_through_the_torchrun_path_with_rccl(cuda):
+    from toad_amd import launch
+    cmd = launch.self_launch_cmd(os.path.join(REPO, "bench.py"), ["--config", "4", "--gpus", "1", "--steps", "2", "--warmup", "1",
+                                                                   "--no-cpu-baseline", "--backend", "nccl"], 1)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]                       # the JSON line is the only thing on stdout (RCCL's banner goes to stderr)
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["scaling"] == "strong" and out["steps"] == 2
+    assert out["config"]["slides_per_step"] == 64 and out["config"]["patches_per_slide"] == 50000
+    assert "torch.distributed.run" in out["config"]["parallelism"]
+    ar = out["allreduce"]
+    assert ar["world"] == 1 and ar["backend"].startswith("nccl") and "error" not in ar and ar["us"] > 0 and ar["unchanged_at_world_1"]
+    assert "communicator" not in ar                                # the group torchrun's rendezvous created was used, not a private one
+    assert out["value"] > 0 and abs(out["value"] - 64 * 1e3 / out["ms_per_step"]) <= 1e-2 * out["value"]
+    for key in ("roofline", "roofline_mfma"):
+        assert 0 < out[key]["frac"] < 1, key
+    assert out["roofline_mfma"]["rows"] == 2 * 64 * 50000

@@ -132,6 +132,49 @@ def test_train_mode_dropout_runs_and_is_seeded(cuda):
     assert not torch.equal(res[0][1], res[2][1]) and torch.isfinite(res[2][1]).all()
 
 
+def test_train_mode_dropout_matches_the_oracle_with_reproduced_masks(cuda):
+    """Train-mode dropout in the ragged step: the trunk masks hash the element index in the CONCATENATION (seeds s1, s2), the pooling masks
+    the index inside each slide with the slide's own pair of seeds (sa + 2bG, sb + 2bG: no slide's tanh mask equals another slide's sigmoid
+    mask). The masks are reproduced with toad_dropout_mask_f32 and fed to the oracle slide by slide: per-slide logits and losses agree."""
+    from toad_amd import functional as F_, ops
+    model, _ = _model(cuda, seed=5, dropout=True)
+    sd = model.state_dict()
+    rename = {"attention_net.3.": "attention_net.2.", "attention_net.6.": "attention_net.4."}      # dropout=True key names -> the oracle's
+    params = {}
+    for k, v in sd.items():
+        for a, b in rename.items():
+            if k.startswith(a):
+                k = b + k[len(a):]
+        params[k] = v.detach().cpu().clone()
+    w = {k: v.detach() for k, v in model._weights().items()}
+    lens = [300, 64, 777, 300]
+    slides = _slides(lens, seed=8)
+    dev = [tuple(t.to(cuda) for t in s) for s in slides]
+    sex = torch.cat([s[1] for s in dev]); label = torch.cat([s[2] for s in dev]); site = torch.cat([s[3] for s in dev])
+    seed, B, ntot = 123456789, len(lens), sum(lens)
+    g = {k: torch.zeros_like(w[k]) for k in ops.STEP_SLOTS}
+    loss, logits, slog = ops.mil_multi_step(w, g, 0.0, [s[0] for s in dev], sex, label, site, 0.75 / B, 0.25 / B, drop_p=F_.DROP_P, seed=seed, want_logits=True)
+    s1, s2, sa, sb = F_.drop_seeds(seed)
+    m_h1 = ops.dropout_mask(ntot * 512, F_.DROP_P, s1, cuda).reshape(ntot, 512).cpu()
+    m_h = ops.dropout_mask(ntot * 512, F_.DROP_P, s2, cuda).reshape(ntot, 512).cpu()
+    G, mask64 = 0x9E3779B97F4A7C15, 0xFFFFFFFFFFFFFFFF
+    off, pool_masks = 0, []
+    for b, (x, sx, lb, st) in enumerate(slides):
+        n = lens[b]
+        mk = {"h1": m_h1[off:off + n], "h": m_h[off:off + n],
+              "a": ops.dropout_mask(n * 384, F_.DROP_P, (sa + 2 * b * G) & mask64, cuda).reshape(n, 384).cpu(),
+              "b": ops.dropout_mask(n * 384, F_.DROP_P, (sb + 2 * b * G) & mask64, cuda).reshape(n, 384).cpu()}
+        pool_masks.append(mk)
+        o_out, o_loss, _ = orc.fwd_bwd(params, x, sx, lb, st, masks=mk)
+        assert (logits[b].cpu() - o_out["logits"][0]).abs().max().item() <= 1e-4, b
+        assert (slog[b].cpu() - o_out["site_logits"][0]).abs().max().item() <= 1e-4, b
+        assert abs(loss[b][0].item() * B - float(o_loss)) <= 1e-4, b
+        off += n
+    # equal-length slides 0 and 3: four different pooling masks, none shared across slides or branches
+    ms = [pool_masks[0]["a"], pool_masks[0]["b"], pool_masks[3]["a"], pool_masks[3]["b"]]
+    assert all(not torch.equal(ms[i], ms[j]) for i in range(4) for j in range(i + 1, 4))
+
+
 def test_train_loop_dp_learns_on_small_bags(cuda):
     """train_loop_dp: one optimiser step per batch of slides through the ragged multi-slide call; the class loss falls on a learnable signal
     and the epoch statistics equal the mean of the per-slide losses the step reports."""

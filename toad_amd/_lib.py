@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TOAD_HIP_LIB", os.path.join(_HERE, "libtoad_hip.so"))   # override: kernel A/B builds only
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 P, I64, I, F, SZ, U64 = c_void_p, c_int64, c_int, c_float, c_size_t, c_uint64
 
@@ -68,7 +68,7 @@ SIGNATURES = {
     "toad_mil_fwd_xp_f32": (I, [P, P, P, P, I64, I, I, F, U64, I, P, SZ, P, SZ, P]),
     "toad_mil_bwd_xp_f32": (I, [P, P, F, P, P, I64, I, I, F, U64, P, SZ, P, P, P, P, P, P, SZ, P]),
     "toad_mil_multi_ws_bytes": (SZ, [I64, I, I, I]),
-    "toad_mil_multi_step_f32": (I, [P, P, F, P, P, I, P, P, P, F, F, I, I, F, U64, P, P, P, P, SZ, P]),
+    "toad_mil_multi_step_f32": (I, [P, P, F, P, P, I, P, P, P, F, F, I, I, F, U64, P, P, P, P, SZ, P, P]),
     "toad_mil_step_xp_f32": (I, [P, P, F, P, P, P, P, P, F, F, I64, I, I, F, U64, P, P, P, P, SZ, P, P]),
 }
 

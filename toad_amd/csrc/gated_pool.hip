@@ -107,7 +107,9 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_fwd_kernel(
         N = (int)(seg[blockIdx.y + 1] - r0);
         Pa += r0 * ldp; Pb += r0 * ldp; A_raw += r0 * T_;
         if (POOL) H += r0 * L_;
-        drop_a.seed += (uint64_t)blockIdx.y * 0x9E3779B97F4A7C15ull; drop_b.seed += (uint64_t)blockIdx.y * 0x9E3779B97F4A7C15ull;
+        // slide y draws its tanh- / sigmoid-branch masks with seeds + 2 y G: the base seeds are seed + 3 G and seed + 4 G (step.hip drop_seeds), so the
+        // tanh seeds stay on odd and the sigmoid seeds on even multiples of G and no slide's mask repeats another slide's other branch
+        drop_a.seed += (uint64_t)blockIdx.y * (2ull * 0x9E3779B97F4A7C15ull); drop_b.seed += (uint64_t)blockIdx.y * (2ull * 0x9E3779B97F4A7C15ull);
     }
     const int pblk = blockIdx.y * gridDim.x + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -391,7 +393,9 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
         if (dH) dH += r0 * L_;
         if (dA_ext) dA_ext += r0 * T_;
         stats += (int64_t)blockIdx.y * s_stride; Mp += (int64_t)blockIdx.y * m_stride; dM += (int64_t)blockIdx.y * m_stride;
-        drop_a.seed += (uint64_t)blockIdx.y * 0x9E3779B97F4A7C15ull; drop_b.seed += (uint64_t)blockIdx.y * 0x9E3779B97F4A7C15ull;
+        // slide y draws its tanh- / sigmoid-branch masks with seeds + 2 y G: the base seeds are seed + 3 G and seed + 4 G (step.hip drop_seeds), so the
+        // tanh seeds stay on odd and the sigmoid seeds on even multiples of G and no slide's mask repeats another slide's other branch
+        drop_a.seed += (uint64_t)blockIdx.y * (2ull * 0x9E3779B97F4A7C15ull); drop_b.seed += (uint64_t)blockIdx.y * (2ull * 0x9E3779B97F4A7C15ull);
     }
     const int pblk = blockIdx.y * gridDim.x + blockIdx.x;
     const bool dropping = drop_a.thresh != 0;

@@ -492,7 +492,8 @@ extern "C" size_t toad_mil_multi_ws_bytes(int64_t Ntot, int B, int C, int D) {
 extern "C" int toad_mil_multi_step_f32(const float *const *params, float *const *grads, float beta, const float *Xcat,
                                         const int64_t *offsets, int B, const float *sex, const int64_t *label, const int64_t *site,
                                         float w_cls, float w_site, int C, int D, float drop_p, uint64_t seed,
-                                        float *loss_out, float *logits_out, float *site_logits_out, void *ws, size_t ws_bytes, void *stream) {
+                                        float *loss_out, float *logits_out, float *site_logits_out, void *ws, size_t ws_bytes, void **events,
+                                        void *stream) {
     const char *what = "toad_mil_multi_step_f32";
     if (!params || !grads || !Xcat || !offsets || !sex || !label || !site || !loss_out || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (B <= 0 || B > 4096) { set_error("%s: B must be in [1, 4096]", what); return TOAD_EINVAL; }
@@ -515,11 +516,19 @@ extern "C" int toad_mil_multi_step_f32(const float *const *params, float *const 
     char *mb = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(sb + w.total) + 255) & ~(uintptr_t)255);
     const MultiSmall ms = multi_small_layout(B, mb);
     hipStream_t st = (hipStream_t)stream;
+    const StreamEvents ev{events, st};
     const int D2 = 2 * D;
     const DropSeeds ds = drop_seeds(drop_p, seed);
     const EpiScalars relu1{1, 1.f, make_drop(drop_p, ds.s1)}, relu2{1, 1.f, make_drop(drop_p, ds.s2)}, lin{0, 1.f, make_drop(0.f, 0)};
     const EpiScalars msk{0, ds.mscale, make_drop(0.f, 0)};
     const H2Pool nopool{nullptr, nullptr, nullptr, 0};
+    // the slides' row offsets go to the device FIRST: the source is the caller's pageable array, so the runtime stages the copy before it
+    // returns and orders it behind whatever the stream already holds - in front of the GEMMs that wait is nothing, behind them it was the
+    // three forward GEMMs on every call (the host lost its launch run-ahead)
+    if (hipMemcpyAsync(ms.seg, offsets, (size_t)(B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess) {
+        set_error("%s: copying the slide offsets to the device failed: %s", what, hipGetErrorString(hipGetLastError()));
+        return TOAD_EINVAL;
+    }
     // ---- forward: one launch splits the five weight operands and zeroes both groups of abs-max arrays; three GEMMs over all rows
     {
         const H2Operand ops5[5] = {{p.w1, kL0, 1, kL, kL0, w.planes[W_1], w.binv[W_1]}, {p.w2, kL, 1, kL, kL, w.planes[W_2], w.binv[W_2]},
@@ -530,37 +539,43 @@ extern "C" int toad_mil_multi_step_f32(const float *const *params, float *const 
         TOAD_TRY(launch_split_h2(ops5, 5, f.amax_x, nz, st, what, w.amax_dP, nzb));
     }
     TOAD_TRY(launch_absmax(Xcat, kL0, N, kL0, f.amax_x, false, st, what));
-    TOAD_TRY(launch_nt_h2(Xcat, kL0, f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h1, f.bits_h1, st, what));
-    TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h, nullptr, st, what));
-    TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nullptr, nopool, w.slabs, nullptr, nullptr, st, what));
+    ev(2); TOAD_TRY(launch_nt_h2(Xcat, kL0, f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h1, f.bits_h1, st, what)); ev(3);
+    ev(4); TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h, nullptr, st, what)); ev(5);
+    ev(6); TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nullptr, nopool, w.slabs, nullptr, nullptr, st, what)); ev(7);
     // ---- all slides at once (blockIdx.y = slide): fused pool forward on each row range + merge; heads + weighted CE + heads backward with
     // one workgroup per slide, then the head-weight gradients summed over the batch; pooling backward (dP rows, the pooling gradient
     // dH_pool rows into the dZ2 buffer, dWc / dbc summed over the batch). Five launches + two small copies, whatever B is - a 64-slide
     // batch of 256-patch bags was 320 launches of mostly idle kernels when this ran slide by slide.
     int64_t max_n = 0;
     for (int b = 0; b < B; ++b) if (offsets[b + 1] - offsets[b] > max_n) max_n = offsets[b + 1] - offsets[b];
-    (void)hipMemcpyAsync(ms.seg, offsets, (size_t)(B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st);      // pageable source: staged before the call returns
     const int rec_f = (int)(kSlideRec / sizeof(float));
-    TOAD_TRY(launch_pool_fwd_batch(f.P, f.P + D, D2, f.H, p.wc, p.bc, f.A_raw, ms.M, rec_f, ms.stats, rec_f, ms.pool_ws, ms.seg, B, max_n, kL, D, kT, drop_p,
-                                   ds.sa, ds.sb, st));
+    ev(0); TOAD_TRY(launch_pool_fwd_batch(f.P, f.P + D, D2, f.H, p.wc, p.bc, f.A_raw, ms.M, rec_f, ms.stats, rec_f, ms.pool_ws, ms.seg, B, max_n, kL, D, kT, drop_p,
+                                   ds.sa, ds.sb, st)); ev(1);
     const HeadsBatch hb{ms.M, ms.Mcat, ms.logits, ms.yprob, ms.yhat, ms.slog, ms.sprob, ms.shat, ms.dM, ms.dl, ms.dsv, kSlideRec};
     TOAD_TRY(launch_heads_batch(hb, sex, p.wcls, p.bcls, p.wsite, p.bsite, label, site, w_cls, w_site, loss_out, grads[8], grads[9], grads[10], grads[11], beta,
                                 B, kL, C, st));
-    if (logits_out) (void)hipMemcpy2DAsync(logits_out, (size_t)C * sizeof(float), ms.logits, kSlideRec, (size_t)C * sizeof(float), B, hipMemcpyDeviceToDevice, st);
-    if (site_logits_out) (void)hipMemcpy2DAsync(site_logits_out, 2 * sizeof(float), ms.slog, kSlideRec, 2 * sizeof(float), B, hipMemcpyDeviceToDevice, st);
+    if (logits_out && hipMemcpy2DAsync(logits_out, (size_t)C * sizeof(float), ms.logits, kSlideRec, (size_t)C * sizeof(float), B, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        set_error("%s: copying the per-slide logits failed: %s", what, hipGetErrorString(hipGetLastError()));
+        return TOAD_EINVAL;
+    }
+    if (site_logits_out && hipMemcpy2DAsync(site_logits_out, 2 * sizeof(float), ms.slog, kSlideRec, 2 * sizeof(float), B, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        set_error("%s: copying the per-slide site logits failed: %s", what, hipGetErrorString(hipGetLastError()));
+        return TOAD_EINVAL;
+    }
     TOAD_TRY(launch_pool_bwd_batch(f.P, f.P + D, D2, f.H, p.wc, f.A_raw, ms.stats, rec_f, ms.M, ms.dM, rec_f, w.dP, w.dP + D, D2, w.dZ2, grads[6], grads[7], beta,
                                    ms.pool_ws, ms.seg, B, max_n, kL, D, kT, drop_p, ds.sa, ds.sb, st));
     // the slides' row ranges do not line up with the 256-row blocks of the concatenation: dP's abs-max array is measured in one pass
     TOAD_TRY(launch_absmax(w.dP, D2, N, D2, w.amax_dP, false, st, what));
     // ---- backward GEMMs over all rows
     WgradDeferred dw[3];
-    TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what, TOAD_X_F32, &dw[0]));
+    ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what, TOAD_X_F32, &dw[0])); ev(9);
     // dZ2 = (dP Wab + dH_pool) * (H > 0), in place over the materialised dH_pool
-    TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, w.dZ2, f.H, nullptr, nopool, w.slabs,
-                          w.amax_dZ2, nullptr, st, what));
-    TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws2, st, what, TOAD_X_F32, &dw[1]));
-    TOAD_TRY(launch_nt_h2(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, f.bits_h1, nopool, w.slabs,
-                          w.amax_dZ1, nullptr, st, what));
-    TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, Xcat, f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws3, st, what, TOAD_X_F32, &dw[2]));
-    return launch_wgrad_reduce(dw, 3, st, what);
+    ev(10); TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, w.dZ2, f.H, nullptr, nopool, w.slabs,
+                                  w.amax_dZ2, nullptr, st, what)); ev(11);
+    ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws2, st, what, TOAD_X_F32, &dw[1])); ev(13);
+    ev(14); TOAD_TRY(launch_nt_h2(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, f.bits_h1, nopool, w.slabs,
+                                  w.amax_dZ1, nullptr, st, what)); ev(15);
+    ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, Xcat, f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws3, st, what, TOAD_X_F32, &dw[2]));
+    TOAD_TRY(launch_wgrad_reduce(dw, 3, st, what)); ev(17);
+    return TOAD_OK;
 }

@@ -83,8 +83,10 @@ class BagPrefetcher:
             bag = t.to(self.device, non_blocking=True)
             if self.dtype is not None and bag.dtype != self.dtype:
                 bag = bag.to(self.dtype)                        # fp16/bf16 on disk: half the PCIe bytes, upcast here
-            if self.prepare and bag.shape[0] >= 64 and bag.shape[1] == 1024:
-                from . import ops
+            from . import ops
+            # only bags the prepared-bag kernels take (32-bit row offsets: < 1,048,576 patches): a larger one stays an fp32 tensor and
+            # runs on the fp32 path instead of raising in the model after its fp32 copy was dropped
+            if self.prepare and bag.dtype == torch.float32 and bag.shape[0] >= 64 and bag.shape[1] == 1024 and ops.x16_ok(bag.shape[0]):
                 bag = ops.prepare_bag(bag)                      # on the copy stream (ops use the current stream); the fp32 bag dies here
             meta_d = meta.to(self.device, non_blocking=True)
             sx_d = sx.to(self.device, non_blocking=True)

@@ -422,9 +422,11 @@ class PreparedBag:
         return self.planes.numel() + 4 * self.amax.numel()
 
 
-def prepare_bag(x: torch.Tensor) -> PreparedBag:
+def prepare_bag(x: torch.Tensor, out: Optional[PreparedBag] = None) -> PreparedBag:
     """fp32 (or fp16 / bf16: up-cast first) bag [N, K] on the device -> PreparedBag. One pass for the abs-max array, one for the
-    split (reads the bag twice, writes it once: ~0.2 ms per 100,000 x 1024 bag, off the training stream when done at ingest)."""
+    split (reads the bag twice, writes it once: ~0.2 ms per 100,000 x 1024 bag, off the training stream when done at ingest).
+    ``out``: a PreparedBag of the same shape whose buffers are overwritten (a double-buffered ingest loop allocates two and
+    alternates; the caller orders the overwrite behind the last step that read them)."""
     if x.dtype != torch.float32:
         x = x.float()
     x = x.contiguous()
@@ -433,10 +435,15 @@ def prepare_bag(x: torch.Tensor) -> PreparedBag:
     if n == 0 or k % 8 != 0:
         raise ValueError("prepare_bag: needs a non-empty [N, K] bag with K a multiple of 8")
     lib = _lib.load()
-    planes = torch.empty(int(lib.toad_bag_planes_bytes(n, k)), dtype=torch.uint8, device=x.device)
-    amax = torch.empty(amax_floats(n), dtype=torch.float32, device=x.device)
+    if out is not None:
+        if tuple(out.shape) != (n, k) or out.planes.device != x.device:
+            raise ValueError("prepare_bag: `out` must be a PreparedBag of the same shape on the same device")
+        planes, amax = out.planes, out.amax
+    else:
+        planes = torch.empty(int(lib.toad_bag_planes_bytes(n, k)), dtype=torch.uint8, device=x.device)
+        amax = torch.empty(amax_floats(n), dtype=torch.float32, device=x.device)
     _lib.check(lib.toad_bag_prepare_f32(_p(x), n, k, _p(planes), _p(amax), _stream()), "toad_bag_prepare_f32")
-    return PreparedBag(planes, amax, n, k)
+    return out if out is not None else PreparedBag(planes, amax, n, k)
 
 
 def _chk_bag(bag) -> int:
@@ -545,10 +552,20 @@ def mil_multi_step(w, grads, beta: float, bags, sex, label, site, w_cls: float =
     logits = torch.empty((nb, c), dtype=torch.float32, device=dev) if want_logits else None
     slog = torch.empty((nb, 2), dtype=torch.float32, device=dev) if want_logits else None
     offs = (ctypes.c_int64 * (nb + 1))(*offsets)
-    with _timed("mil_multi_step"):
-        _lib.check(lib.toad_mil_multi_step_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(xcat), offs, nb, _p(sex), _p(label), _p(site),
-                                               float(w_cls), float(w_site), c, d, float(drop_p), int(seed), _p(loss), _p(logits), _p(slog),
-                                               _p(ws), ws.numel(), _stream()), "toad_mil_multi_step_f32")
+    events = None
+    ev_objs = None
+    if _TIMING is not None:                                  # same 18-event layout as mil_step: pool forward, then the eight GEMM calls
+        nev = 18 if _TIMING_LEVEL >= 2 else 2
+        ev_objs = [_take_event() for _ in range(nev)]
+        events = (ctypes.c_void_p * 18)(*([e.cuda_event for e in ev_objs] + [None] * (18 - nev)))
+    _lib.check(lib.toad_mil_multi_step_f32(_ptr_array(ws_t), _ptr_array(gs_t), float(beta), _p(xcat), offs, nb, _p(sex), _p(label), _p(site),
+                                           float(w_cls), float(w_site), c, d, float(drop_p), int(seed), _p(loss), _p(logits), _p(slog),
+                                           _p(ws), ws.numel(), events, _stream()), "toad_mil_multi_step_f32")
+    if ev_objs is not None:
+        _TIMING.setdefault("pool_fwd", []).append((ev_objs[0], ev_objs[1]))
+        if len(ev_objs) == 18:
+            for i, name in enumerate(_GEMM_EVENT_NAMES):
+                _TIMING.setdefault(name, []).append((ev_objs[2 + 2 * i], ev_objs[3 + 2 * i]))
     return loss, logits, slog
 
 
