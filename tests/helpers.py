@@ -140,10 +140,10 @@ def assert_grad_close_or_few_flips(got, ref, rel, scale, what="", floor=0.0, max
     return 1
 
 
-def relu_flips(params, x, h1_dev, h_dev):
-    """Positions where the device's ReLU masks (h1 > 0, h > 0) differ from the masks of the exact (fp64) forward, and a check
-    that every such flip is LEGITIMATE: the exact pre-activation there is within fp32 round-off of zero (two correct fp32
-    implementations can land on either side). Returns the number of flips. models/model_toad.py:59-64."""
+def relu_flip_positions(params, x, h1_dev, h_dev):
+    """Positions [k, 2] = (patch, unit) where the device's ReLU masks (h1 > 0, h > 0) differ from the masks of the exact (fp64) forward,
+    and a check that every such flip is LEGITIMATE: the exact pre-activation there is within fp32 round-off of zero (two correct fp32
+    implementations can land on either side). models/model_toad.py:59-64."""
     p = {k: v.double() for k, v in params.items()}
     z1 = torch.addmm(p["attention_net.0.bias"], x.double(), p["attention_net.0.weight"].t())
     h1d = h1_dev.detach().cpu()
@@ -155,7 +155,91 @@ def relu_flips(params, x, h1_dev, h_dev):
         if f.any():
             worst = z[f].abs().max().item()
             assert worst <= 2e-5 * max(z.abs().max().item(), 1e-30), f"{nm}: mask flip at |pre-activation| = {worst:.3e} is not round-off"
-    return int(f1.sum()), int(f2.sum())
+    return f1.nonzero(), f2.nonzero()
+
+
+def relu_flips(params, x, h1_dev, h_dev):
+    """Number of legitimate ReLU-mask flips in layer 1 and layer 2 (relu_flip_positions)."""
+    i1, i2 = relu_flip_positions(params, x, h1_dev, h_dev)
+    return int(i1.shape[0]), int(i2.shape[0])
+
+
+TRUNK_KEYS = ("attention_net.0.weight", "attention_net.0.bias", "attention_net.2.weight", "attention_net.2.bias")
+
+
+def check_trunk_grads_vs_golden_blocks(golden, name, grads, x, flips1, flips2):
+    """The four trunk gradients against the REFERENCE's fp64 values (fixture matrices grad_block64/*), tolerant of exactly what the known
+    legitimate ReLU-mask flips can do and of nothing else (models/model_toad.py:59-64 under autograd):
+      * a layer-2 flip at (patch n, unit j) changes dZ2[n, j] only: dW2 row j and db2[j] move, every other row / entry must match;
+        through dZ1[n, :] = (dZ2[n, :] W2) * mask1 it adds ONE rank-one term c x_n^T to dW1 (x_n = the patch's feature row, known)
+        and the column c to db1;
+      * a layer-1 flip at (n, j) changes dZ1[n, j] only: dW1 row j and db1[j].
+    So: rows of dW2 / entries of db2 outside the flipped units are held to the reference; rows of the dW1 block outside the layer-1
+    flipped units are held to it after removing their component in span{x_n : layer-2 flips} (at most a few dozen of 1024 directions),
+    and the coefficients that projection finds must explain db1's deviation on the same rows. Returns the number of block rows checked."""
+    pre = name + "/"
+    w1k, b1k, w2k, b2k = TRUNK_KEYS
+    if pre + "grad_block64/" + w1k not in golden.files:
+        return 0
+    onoise = oracle_fp32_noise(golden, name)
+
+    def tol_of(k):
+        dev = max(float(golden[pre + "grad_dev64/" + k]), onoise[k])
+        # the same bound check_outputs_vs_golden uses - except that grad_dev64 of a flip-affected gradient already CONTAINS the
+        # reference's own fp32 flips; cap the noise term so that it cannot swallow a real error on an unaffected row
+        return max(2e-5, min(10.0 * dev / max(float(golden[pre + "grad_absmax/" + k]), 1e-300), 2e-4)) * float(golden[pre + "grad_absmax/" + k])
+
+    u1 = set(int(j) for j in flips1[:, 1].tolist()) if len(flips1) else set()
+    u2 = set(int(j) for j in flips2[:, 1].tolist()) if len(flips2) else set()
+    checked = 0
+    # ---- layer 2: rows / entries outside the flipped units
+    g2 = grads[w2k].detach().cpu().double()
+    ref2 = torch.from_numpy(golden[pre + "grad_block64/" + w2k]).double()
+    rows2 = [r for r in range(ref2.shape[0]) if r not in u2]
+    e2 = (g2[:ref2.shape[0]] - ref2)[rows2]
+    assert float(e2.abs().max()) <= tol_of(w2k), f"{name}: dW2 rows without a flipped unit deviate from the reference by {float(e2.abs().max()):.3e} (tol {tol_of(w2k):.3e})"
+    checked += len(rows2)
+    gb2 = grads[b2k].detach().cpu().double()
+    refb2 = torch.from_numpy(golden[pre + "grad_block64/" + b2k]).double()
+    keep = torch.tensor([j not in u2 for j in range(512)])
+    assert float((gb2 - refb2)[keep].abs().max()) <= tol_of(b2k), f"{name}: db2 entries without a flipped unit deviate from the reference"
+    # ---- layer 1: block rows outside the layer-1 flipped units, minus their component along the layer-2 flipped patches' feature rows
+    g1 = grads[w1k].detach().cpu().double()
+    ref1 = torch.from_numpy(golden[pre + "grad_block64/" + w1k]).double()
+    rows1 = [r for r in range(ref1.shape[0]) if r not in u1]
+    e1 = (g1[:ref1.shape[0]] - ref1)[rows1]
+    gb1 = grads[b1k].detach().cpu().double()
+    eb1 = (gb1 - torch.from_numpy(golden[pre + "grad_block64/" + b1k]).double())[rows1]
+    patches = sorted(set(int(n) for n in flips2[:, 0].tolist())) if len(flips2) else []
+    if patches:
+        xs = x[patches].double()                                  # [k, 1024]
+        coef = torch.linalg.lstsq(xs.t(), e1.t()).solution.t()    # [rows, k]: e1 ~ coef @ xs
+        explained = coef @ xs
+        scale1 = float(golden[pre + "grad_absmax/" + w1k])
+        assert float(explained.abs().max()) <= 5e-2 * scale1, f"{name}: the part of dW1's deviation along the flipped patches is {float(explained.abs().max()) / scale1:.2e} of its scale"
+        e1 = e1 - explained
+        eb1 = eb1 - coef.sum(1)                                   # the same dZ1 rows summed give db1's deviation
+    assert float(e1.abs().max()) <= tol_of(w1k), f"{name}: dW1 block deviates from the reference by {float(e1.abs().max()):.3e} beyond what {len(patches)} flipped patches explain (tol {tol_of(w1k):.3e})"
+    assert float(eb1.abs().max()) <= tol_of(b1k) + 1e-6 * float(golden[pre + "grad_absmax/" + w1k]), f"{name}: db1 deviates from the reference by {float(eb1.abs().max()):.3e} beyond the flips' contribution"
+    return checked + len(rows1)
+
+
+def check_activations_vs_golden(golden, name, h1_dev, h_dev, atol=1e-4):
+    """H1 / H of the device forward against strided samples (and sums) of the reference's own activations, captured with forward hooks
+    on its two ReLU modules (models/model_toad.py:59-64) - for the cases the fixture carries them (the BASELINE sizes)."""
+    pre = name + "/"
+    if pre + "act_sample/h1" not in golden.files:
+        return False
+    for k, t in (("h1", h1_dev), ("h", h_dev)):
+        t = t.detach().cpu()
+        ref = golden[pre + "act_sample/" + k]
+        scale = max(float(golden[pre + "act_absmax/" + k]), 1.0)
+        assert_close(strided_sample(t, ref.shape[0]), ref, atol * scale, what=f"{name}:{k} sample")
+        assert abs(float(t.abs().max()) - float(golden[pre + "act_absmax/" + k])) <= atol * scale, (name, k)
+        s, ss = float(t.double().sum()), float((t.double() ** 2).sum())
+        assert abs(s - float(golden[pre + "act_sum/" + k])) <= 1e-6 * abs(float(golden[pre + "act_sum/" + k])) + 1e-3, (name, k, "sum")
+        assert abs(ss - float(golden[pre + "act_sumsq/" + k])) <= 2e-6 * float(golden[pre + "act_sumsq/" + k]) + 1e-3, (name, k, "sumsq")
+    return True
 
 
 # Which gradients a ReLU-mask flip can reach. The masks enter the backward only where dZ = dH * (H > 0) is formed
