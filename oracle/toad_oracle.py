@@ -308,3 +308,28 @@ def xavier_params(n_classes: int, seed: int = 1, size_arg: str = "big") -> Dict[
         else:
             out[k] = torch.zeros(shp)
     return out
+
+
+def xavier_params_like_reference(n_classes: int, seed: int = 1, size_arg: str = "big") -> Dict[str, torch.Tensor]:
+    """The parameters the reference model starts from under ``torch.manual_seed(seed)``, bit for bit (checked against the imported
+    reference by oracle/pin_config1_against_reference.py): models/model_toad.py:54-75 builds its nn.Linear layers in this order - each
+    constructor draws its default kaiming-uniform weight and uniform bias from the global generator - and then
+    utils/utils.py:150-154 initialize_weights re-draws every weight with xavier_normal_ in ``modules()`` order and zeroes the biases."""
+    l0, l, d = {"small": (1024, 512, 256), "big": (1024, 512, 384)}[size_arg]
+    state = torch.get_rng_state()
+    try:
+        torch.manual_seed(seed)
+        layers = [("attention_net.0", torch.nn.Linear(l0, l)), ("attention_net.2", torch.nn.Linear(l, l)),
+                  ("attention_net.4.attention_a.0", torch.nn.Linear(l, d)), ("attention_net.4.attention_b.0", torch.nn.Linear(l, d)),
+                  ("attention_net.4.attention_c", torch.nn.Linear(d, 2)), ("classifier", torch.nn.Linear(l + 1, n_classes)),
+                  ("site_classifier", torch.nn.Linear(l + 1, 2))]
+        out = {}
+        for name, lin in layers:
+            torch.nn.init.xavier_normal_(lin.weight)
+            out[name + ".weight"] = lin.weight.detach().clone()
+            out[name + ".bias"] = torch.zeros_like(lin.bias)
+    finally:
+        torch.set_rng_state(state)
+    assert set(out) == set(PARAM_KEYS)
+    return out
+
