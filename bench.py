@@ -497,7 +497,19 @@ def main():
         n = args.patches or 50_000
         global_slides = 64
         mine = shard_round_robin(global_slides, rank, world)           # slide i -> rank i mod G
-        slides = [[make_slide(i, n, dev) for i in mine]]               # the same 64 resident slides every step
+        # the rank's bags lie back to back in ONE resident buffer (what an ingest buffer filled slide after slide looks like): the ragged
+        # multi-slide call takes consecutive bags as their own concatenation, without copying a row (ops._adjacent_rows)
+        pool = torch.empty((len(mine) * n, L0), device=dev, dtype=BAG_DTYPE)
+        slides = [[]]
+        for s_, i in enumerate(mine):
+            bag, sex_, label_, site_ = make_slide(i, n, dev)
+            if getattr(bag, "is_prepared_bag", False):                 # --bag-format prepared: per-slide calls on prepared bags
+                slides[0].append((bag, sex_, label_, site_))
+                continue
+            view = pool[s_ * n:(s_ + 1) * n]
+            view.copy_(bag)
+            slides[0].append((view, sex_, label_, site_))             # the same 64 resident slides every step
+            del bag
         nbags = 1
         scaling = "strong"
     else:
@@ -607,8 +619,9 @@ def main():
                        "arithmetic": "fp32 storage/accumulation; GEMM operands as two fp16 pieces (x*s = h+m, power-of-two scales), 3 MFMA terms = "
                                      "fp32-equivalent, verified vs fp64 (tools/split_emulation.py, tests/test_gpu_h2.py)",
                        "patches_per_slide": n, "slides_per_step": global_slides,
-                       "batching": ("one ragged multi-slide call per rank and step (toad_mil_multi_step_f32: trunk / attention GEMMs once over the "
-                                    "concatenated bags, pooling + heads + loss per slide; the concatenation is inside the timed step)"
+                       "batching": ("consecutive slides of a rank share ragged multi-slide calls of at most 131,072 rows (toad_mil_multi_step_f32: trunk / "
+                                    "attention GEMMs once over the concatenated bags, pooling + heads + loss per slide; bags that are not already "
+                                    "adjacent in memory are concatenated inside the timed step)"
                                     if batched else "one library call per slide"),
                        "parallelism": f"slide-sharded dp{world}, one {4 * model.flat_parameters().numel() / 1e6:.2f} MB grad all-reduce/step"
                                       + (" (issued at world 1 too: started by torch.distributed.run)" if under_torchrun and world == 1 else "")},

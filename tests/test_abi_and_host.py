@@ -160,3 +160,21 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_adjacent_bags_are_their_own_concatenation():
+    """ops._adjacent_rows: consecutive row ranges of one allocation go to the ragged multi-slide call as a VIEW (no torch.cat copy); anything
+    else (a gap, another allocation, another dtype, a permuted order) is not adjacent and gets concatenated as before."""
+    import torch
+    from toad_amd import ops
+    pool = torch.arange(10 * 8, dtype=torch.float32).reshape(10, 8)
+    a, b, c = pool[0:3], pool[3:4], pool[4:10]
+    v = ops._adjacent_rows([a, b, c])
+    assert v is not None and v.shape == (10, 8) and v.data_ptr() == pool.data_ptr() and torch.equal(v, pool)
+    assert ops._adjacent_rows([pool[2:5], pool[5:9]]).data_ptr() == pool[2:].data_ptr()
+    assert ops._adjacent_rows([a, c]) is None                               # a gap
+    assert ops._adjacent_rows([b, a]) is None                               # wrong order
+    assert ops._adjacent_rows([a, b.clone()]) is None                       # another allocation
+    assert ops._adjacent_rows([pool.half()[0:3], pool.half()[3:4]]) is None  # not fp32
+    assert ops._adjacent_rows([a, pool[3:4, :4]]) is None                   # another width / non-contiguous
+

@@ -117,6 +117,29 @@ def test_dp_step_batches_small_slides(cuda):
     assert (outs[0] - outs[1]).abs().max().item() <= 5e-5 * sc
 
 
+def test_adjacent_bags_run_without_a_copy_and_give_the_same_gradients(cuda):
+    """Bags cut from one resident buffer (bench.py config 4, an ingest buffer) are taken as their own concatenation: bitwise the results of the
+    same bags passed as separate tensors (which torch.cat copies), and SlideShardedDP batches two 50,000-patch slides into one call."""
+    from toad_amd import ops
+    from toad_amd.dp import SlideShardedDP
+    model, _ = _model(cuda, seed=6)
+    w = {k: v.detach() for k, v in model._weights().items()}
+    lens = [700, 64, 1300]
+    pool = torch.randn(sum(lens), 1024, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
+    views, off = [], 0
+    for n in lens:
+        views.append(pool[off:off + n]); off += n
+    sex = torch.tensor([0.0, 1.0, 1.0], device=cuda); label = torch.tensor([1, 5, 9], device=cuda); site = torch.tensor([0, 1, 0], device=cuda)
+    res = []
+    for bags in (views, [v.clone() for v in views]):
+        g = {k: torch.zeros_like(w[k]) for k in ops.STEP_SLOTS}
+        loss, _, _ = ops.mil_multi_step(w, g, 0.0, bags, sex, label, site, 0.25, 0.08)
+        res.append((loss.clone(), {k: v.clone() for k, v in g.items()}))
+    assert torch.equal(res[0][0], res[1][0]) and all(torch.equal(res[0][1][k], res[1][1][k]) for k in ops.STEP_SLOTS)
+    assert ops._adjacent_rows(views).data_ptr() == pool.data_ptr()
+    assert SlideShardedDP.BATCH_MAX_PATCHES >= 50000 and 2 * 50000 <= SlideShardedDP.BATCH_ROWS
+
+
 def test_train_mode_dropout_runs_and_is_seeded(cuda):
     from toad_amd import ops
     model, _ = _model(cuda, seed=2, dropout=True)

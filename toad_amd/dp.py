@@ -148,8 +148,10 @@ class SlideShardedDP:
             raise RuntimeError("SlideShardedDP: the model's flat parameter buffer was replaced after construction "
                                "(model.to()/deepcopy/re-flatten); build a new SlideShardedDP for the moved model")
 
-    # slides of at most this many patches are batched into one ragged multi-slide call, up to BATCH_ROWS rows per call
-    BATCH_MAX_PATCHES = 32768
+    # slides of at most this many patches are batched into one ragged multi-slide call, up to BATCH_ROWS rows per call. 65,536 lets PAIRS of
+    # 50,000-patch slides (BASELINE config 4) share their GEMM launches: one 50k-patch bag is 392 tiles on 256 CUs (1.5 rounds: half a round of
+    # idle CUs in each of its five row-parallel GEMMs), two are 782 (3.05 rounds) - measured 1.29 -> 1.17 ms per slide (profiles/r04d).
+    BATCH_MAX_PATCHES = 65536
     BATCH_ROWS = 131072
 
     def accumulate(self, slides: Sequence[Slide], global_slides: int, overwrite: bool = True, batched: Optional[bool] = None):

@@ -514,6 +514,23 @@ def mil_step(w, grads, beta: float, bag, sex, label, site, w_cls: float = 0.75, 
     return loss, logits, slog
 
 
+def _adjacent_rows(bags):
+    """Bags that already lie back to back in ONE allocation (an ingest buffer filled slide after slide, or views cut from a concatenated
+    tensor) are their own concatenation: return it as a view, or None. Saves the copy of every bag row that torch.cat would make."""
+    first = bags[0]
+    if first.dtype != torch.float32 or first.dim() != 2:
+        return None
+    store = first.untyped_storage().data_ptr()
+    nxt, rows = first.data_ptr() + first.numel() * 4, first.shape[0]
+    for b in bags[1:]:
+        if b.dtype != torch.float32 or b.dim() != 2 or b.shape[1] != first.shape[1] or not b.is_contiguous() \
+                or b.untyped_storage().data_ptr() != store or b.data_ptr() != nxt:
+            return None
+        nxt += b.numel() * 4
+        rows += b.shape[0]
+    return torch.as_strided(first, (rows, first.shape[1]), (first.shape[1], 1))
+
+
 def mil_multi_step(w, grads, beta: float, bags, sex, label, site, w_cls: float = 0.75, w_site: float = 0.25,
                    drop_p: float = 0.0, seed: int = 0, want_logits: bool = False, offsets=None):
     """forward + weighted CE + backward for a BATCH of slides in ONE library call (toad_mil_multi_step_f32): the trunk / attention GEMMs
@@ -527,7 +544,9 @@ def mil_multi_step(w, grads, beta: float, bags, sex, label, site, w_cls: float =
         offsets = [0]
         for b in bags:
             offsets.append(offsets[-1] + int(b.shape[0]))
-        xcat = bags[0] if len(bags) == 1 else torch.cat(bags, 0)
+        xcat = bags[0] if len(bags) == 1 else _adjacent_rows(bags)
+        if xcat is None:
+            xcat = torch.cat(bags, 0)
     else:
         xcat = bags
         offsets = [int(o) for o in offsets]
