@@ -50,7 +50,10 @@ for i in range(cases):
             og = orc.backward({k: v.double() for k, v in params.items()}, sv64, dl.double(), ds.double())
             ref_noise = {k: (o32[k].double() - og[k]).abs().max().item() for k in og}
         else:
-            ok = ok and torch.equal(res["logits"].detach(), keep["logits"]) and torch.equal(res["A"].detach(), keep["A"])
+            # prepared vs raw fp32 bag: a few ulp (the raw bag is scaled from each tile's first columns inside the GEMM, the prepared one with each
+            # tile's maximum: tests/test_gpu_pt.py ROUTE_TOL)
+            for kk in ("logits", "A"):
+                ok = ok and (res[kk].detach() - keep[kk]).abs().max().item() <= 5e-6 * max(keep[kk].abs().max().item(), 1e-30)
         worst = 0.0
         for k, p in model.named_parameters():
             scale = og[k].abs().max().item()

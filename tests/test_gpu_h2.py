@@ -1,5 +1,7 @@
 """GPU: the fp16 two-piece GEMM path (csrc/gemm_h2.inc) - abs-max plumbing, power-of-two scales, the recomputed pooling addend -
 and the whole-slide entry points (toad_mil_fwd_f32 / toad_mil_bwd_f32) against the per-op path and the oracle."""
+import math
+
 import pytest
 import torch
 
@@ -403,3 +405,61 @@ def test_tn_attention_weighted_rows_spanning_ten_decades(cuda, prepared):
     assert viol <= 0.0, viol
     assert ((dw.cpu().double() - ref).abs().max() / ref.abs().max()).item() <= 1e-6        # and it is fp32-accurate at the tensor's scale
     assert (db.cpu().double() - dy.double().sum(0)).abs().max().item() <= 8 * _EPS * ady.sum(0).max().item()
+
+
+@pytest.mark.parametrize("m", [300, 9000, 70000])
+@pytest.mark.parametrize("kind", ["normal", "late_outliers", "decades"])
+def test_first_gemm_measures_a_raw_bag_itself(cuda, m, kind):
+    """x_amax = None: the GEMM measures its fp32 A operand while it stages it (gemm_h2.inc AMODE 3) - an item's scale from its first 32 columns
+    with three bits of room; an item whose later columns outgrow that room is POISONED and repeated in a second pass with its true exponent.
+    Checked against fp64 with the bound of the two-piece arithmetic, against the route that is handed the abs-max array (a few ulp), and the
+    abs-max array the whole-slide forward leaves in its arena against absmax_rows256 (bitwise: the weight gradient scales the bag with it).
+    Shapes: 300 rows = K-split slices only; 9,000 = slices of remainder tiles; 70,000 = whole tiles + slices.
+    late_outliers: leading columns ~1e-3, values up to 4e3 further right in a third of the row tiles (every such item must be repeated);
+    decades: log-normal features over eight decades."""
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(m + len(kind))
+    k, n = 1024, 512
+    x = torch.randn(m, k, generator=g)
+    if kind == "late_outliers":
+        x[:, :64] *= 1e-3
+        blocks = torch.arange((m + 255) // 256)
+        for b in blocks[blocks % 3 == 1].tolist():
+            r = torch.randint(b * 256, min(m, b * 256 + 256), (5,), generator=g)
+            c = torch.randint(100, k, (5,), generator=g)
+            x[r, c] = torch.tensor([4e3, -2.5e3, 900.0, 1.7e3, -3e3])
+    elif kind == "decades":
+        x = x.sign() * torch.exp(torch.randn(m, k, generator=g) * 4.0)
+    w = torch.randn(n, k, generator=g) * 0.03
+    b = torch.randn(n, generator=g) * 0.05
+    xg, wg, bg = x.to(cuda), w.to(cuda), b.to(cuda)
+    y_run = ops.linear_act_fwd(xg, wg, bg, ops.ACT_NONE)                               # measured inside
+    y_arr = ops.linear_act_fwd(xg, wg, bg, ops.ACT_NONE, x_amax=ops.absmax_rows256(xg))   # handed the array
+    ref = torch.addmm(b.double(), x.double(), w.double().t())
+    assert torch.isfinite(y_run).all()
+    # two-piece bound (test_gpu_h2.py above): c eps sum|ab| + 2^-35 (amax_A sum|b| + ...): rows are independent, take the row-wise form
+    sab = x.double().abs() @ w.double().abs().t()
+    blk_max = torch.stack([x[i:i + 256].abs().max() for i in range(0, m, 256)]).double().repeat_interleave(256)[:m, None]
+    # (_nt_bound's form; the absolute term of A is 2^-35 here: three bits of room above an item's first stage. c = 36 instead of 24: the
+    #  statistical accumulation term is asked to hold for up to 36 M outputs, 70 x the sample of the tests above)
+    w_row_amax = w.double().abs().max(1).values[None, :]
+    bound = 1.5 * max(6.0, 0.75 * math.sqrt(k)) * 2.0 ** -24 * sab + 2.0 ** -35 * blk_max * w.double().abs().sum(1)[None, :] \
+        + 2.0 ** -38 * x.double().abs().sum(1)[:, None] * w_row_amax + 1e-30
+    assert ((y_run.cpu().double() - ref).abs() <= bound).all(), ((y_run.cpu().double() - ref).abs() / bound).max().item()
+    sc = ref.abs().max().item()
+    assert (y_run - y_arr).abs().max().item() <= 5e-6 * sc
+    # run-to-run determinism (the redo pass and the slab alignment are fixed-order)
+    assert torch.equal(y_run, ops.linear_act_fwd(xg, wg, bg, ops.ACT_NONE))
+
+
+@pytest.mark.parametrize("n", [777, 9000, 70000])
+def test_whole_slide_forward_leaves_the_bags_abs_max_array(cuda, n):
+    """toad_mil_fwd_f32 on a raw fp32 bag runs no abs-max pass: the first GEMM's by-product must be exactly the array absmax_rows256 gives."""
+    from toad_amd import ops
+    model, _, x = _model_and_bag(cuda, n, seed=n + 1)
+    x = x.clone(); x[:, :40] *= 1e-4; x[n // 2, 900] = 777.0                            # one poisoned item among ordinary ones
+    w = {k: v.detach() for k, v in model._weights().items()}
+    xg = x.to(cuda)
+    arena = ops.mil_fwd(w, xg, torch.ones(1, device=cuda))
+    assert torch.equal(arena.view("x_amax", (ops.amax_floats(n),)), ops.absmax_rows256(xg))
+

@@ -9,6 +9,21 @@ from tests.helpers import assert_grad_close
 
 pytestmark = pytest.mark.gpu
 
+# Since round 4 a RAW fp32 bag is measured inside the first GEMM (gemm_h2.inc AMODE 3: each tile's scale comes from its first 32 columns with
+# three bits of room) while a prepared bag carries planes scaled with each row tile's true maximum. The two scales differ by a power of two, so
+# the (h, m) pieces have identical significands wherever they are normal fp16 numbers; only second pieces more than 2^14 below a tile's scale
+# (elements ~1e-4 of the maximum) round differently. The two routes therefore agree to a few ulp, not bit for bit: 5e-6 of each tensor's
+# scale here (1e-4 is the parity bound against the reference; run-to-run determinism of EACH route stays bitwise).
+ROUTE_TOL = 5e-6
+
+
+def assert_routes_agree(a, b, what=""):
+    if not a.is_floating_point():
+        assert torch.equal(a, b), what
+        return
+    sc = max(a.abs().max().item(), 1e-30)
+    assert (a - b).abs().max().item() <= ROUTE_TOL * sc, (what, (a - b).abs().max().item(), sc)
+
 
 def decode_planes(pb):
     """PreparedBag -> the fp64 values its (h, m) planes represent, [N, K]: undoes the tiling
@@ -71,22 +86,22 @@ def _step(model, bag, dev):
 
 @pytest.mark.parametrize("n", [64, 300, 777, 2049, 9000, 70000])
 def test_step_on_a_prepared_bag_equals_the_fp32_bag(cuda, n):
-    """toad_mil_step_xp_f32 == toad_mil_step_f32: the planes hold exactly the pieces the fp32 kernels derive every step, the products
-    and their order are the same, so the forward (first Linear by LDS-DMA of the planes) is bitwise equal; the weight gradient of
-    the first layer (transposing reads, per-row-tile exponents) agrees to fp32 round-off of its own scale."""
+    """toad_mil_step_xp_f32 vs toad_mil_step_f32: the planes hold the pieces the fp32 kernels derive every step up to the power of two of the
+    scale (see ROUTE_TOL above), the products and their order are the same: every output and gradient agrees to a few ulp of its scale."""
     from toad_amd import ops
     model, x = _setup(cuda, n, seed=n)
     l0, lg0, sl0, g0 = _step(model, x, cuda)
     pb = ops.prepare_bag(x)
     l1, lg1, sl1, g1 = _step(model, pb, cuda)
-    assert torch.equal(lg0, lg1) and torch.equal(sl0, sl1) and torch.equal(l0, l1)
+    assert_routes_agree(lg0, lg1, "logits"); assert_routes_agree(sl0, sl1, "site logits"); assert_routes_agree(l0, l1, "loss")
     for k in ops.STEP_SLOTS:
-        if k in ("w1", "b1"):
+        if k == "bc":                                           # exactly zero by the softmax's shift invariance: round-off of dWc-sized terms
+            assert (g0[k] - g1[k]).abs().max().item() <= ROUTE_TOL * g0["wc"].abs().max().item(), k
             continue
-        assert torch.equal(g0[k], g1[k]), k                     # everything downstream of H1 saw identical inputs
-    sc = g0["w1"].abs().max().item()
-    assert (g0["w1"] - g1["w1"]).abs().max().item() <= 2e-6 * sc
-    assert (g0["b1"] - g1["b1"]).abs().max().item() <= 2e-6 * max(g0["b1"].abs().max().item(), 1e-30)
+        if k == "bab":                                          # column sums of dP that cancel almost completely: round-off of the cancelling terms
+            assert (g0[k] - g1[k]).abs().max().item() <= 5e-5 * g0[k].abs().max().item(), k
+            continue
+        assert_routes_agree(g0[k], g1[k], k)
     # run-to-run determinism of the prepared path
     l2, lg2, sl2, g2 = _step(model, pb, cuda)
     assert all(torch.equal(g1[k], g2[k]) for k in ops.STEP_SLOTS) and torch.equal(l1, l2)
@@ -135,9 +150,14 @@ def test_module_forward_backward_on_a_prepared_bag(cuda, n):
         outs.append((r, {k: p.grad.clone() for k, p in model.named_parameters()}))
     (r0, g0), (r1, g1) = outs
     for k in ("logits", "Y_prob", "site_logits", "site_prob", "A", "features", "Y_hat", "site_hat"):
-        assert torch.equal(r0[k], r1[k]), k
+        assert_routes_agree(r0[k], r1[k], k)
     for k in g0:
-        sc = max(g0[k].abs().max().item(), 1e-30)
-        assert (g0[k] - g1[k]).abs().max().item() <= 2e-6 * sc, k
+        if k.endswith("attention_c.bias"):
+            assert (g0[k] - g1[k]).abs().max().item() <= ROUTE_TOL * g0[k.replace("bias", "weight")].abs().max().item(), k
+            continue
+        if k.endswith("attention_a.0.bias") or k.endswith("attention_b.0.bias"):     # cancellation-dominated column sums (tests/test_gpu_model.py)
+            assert (g0[k] - g1[k]).abs().max().item() <= 5e-5 * g0[k].abs().max().item(), k
+            continue
+        assert_routes_agree(g0[k], g1[k], k)
     with torch.no_grad():
-        assert torch.equal(model(x, sex, attention_only=True), model(ops.prepare_bag(x), sex, attention_only=True))
+        assert_routes_agree(model(x, sex, attention_only=True), model(ops.prepare_bag(x), sex, attention_only=True), "attention_only")

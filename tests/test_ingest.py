@@ -109,7 +109,8 @@ def test_copies_overlap_with_compute(cuda):
 @pytest.mark.gpu
 def test_prefetcher_prepares_bags_on_the_copy_stream(cuda):
     """BagPrefetcher(prepare=True) yields PreparedBag objects (toad_bag_prepare_f32 on the copy stream, behind the H2D copy): a
-    training step on them gives the loss and logits of the fp32 tensors bitwise, in record order, with copies still in flight."""
+    training step on them gives the loss and logits of the fp32 tensors (to the few ulp by which the two operand routes differ:
+    tests/test_gpu_pt.py ROUTE_TOL), in record order, with copies still in flight."""
     from toad_amd import TOAD_fc_mtl_concat, ops
     from toad_amd.ingest import BagPrefetcher
     recs = _records(5, rows=700)
@@ -130,6 +131,7 @@ def test_prefetcher_prepares_bags_on_the_copy_stream(cuda):
     assert getattr(first, "is_prepared_bag", False) and first.shape == (700, 1024)
     prep = losses(prep_loader)
     for a, b in zip(plain, prep):
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        for u, v in zip(a, b):
+            assert (u - v).abs().max().item() <= 5e-6 * max(u.abs().max().item(), 1e-30)
     with pytest.raises(ValueError):
         BagPrefetcher(recs, cuda, dtype=torch.float16, prepare=True)

@@ -68,6 +68,18 @@ __device__ __forceinline__ float h2_wave_max(float v) {          // wave-wide ma
     for (int o = 32; o > 0; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o));
     return v;
 }
+// the same without lane-index registers (ds_bpermute needs one VGPR per shuffle distance: inside a GEMM main loop that runs at the register
+// limit they spill): DPP inside the 16-lane rows, then the four row results through scalar registers. Every lane returns the wave maximum.
+__device__ __forceinline__ float h2_wave_max_dpp(float v) {
+    v = __builtin_fmaxf(v, dpp_mov<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = __builtin_fmaxf(v, dpp_mov<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = __builtin_fmaxf(v, dpp_mov<0x141>(v));   // row_half_mirror
+    v = __builtin_fmaxf(v, dpp_mov<0x140>(v));   // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)),
+                r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return __builtin_fmaxf(__builtin_fmaxf(r0, r1), __builtin_fmaxf(r2, r3));
+}
 __device__ __forceinline__ void h2_atomic_amax(float *slot, float v) {     // v >= 0
     atomicMax(reinterpret_cast<unsigned *>(slot), __builtin_bit_cast(unsigned, v));
 }
@@ -91,6 +103,7 @@ struct H2Operand { const float *src; int64_t sn, sk; int64_t N, K; unsigned shor
 struct H2Pool { const float *a_raw, *stats, *dM; int T; };                                                   // recomputed pooling addend (T = 0: none)
 struct EpiScalars { int relu; float mask_scale; DropArgs drop; };                                            // epilogue scalars of every NT kernel
 bool h2_nt_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc);
+bool nt_run_ok(int64_t M, int64_t N, int64_t K);       // the first GEMM may measure its fp32 A operand itself (gemm_h2.inc AMODE 3)
 size_t h2_planes_bytes(int64_t N, int64_t K);
 size_t h2_binv_bytes(int64_t N);
 size_t h2_slab_bytes();
@@ -100,7 +113,8 @@ int launch_absmax(const float *X, int64_t ld, int64_t M, int64_t K, float *amax,
 int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C,
                  int64_t ldc, int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
                  const float *mask_src, const unsigned long long *mask_bits, H2Pool pool, float *slabs, float *y_amax,
-                 unsigned long long *bits_out, hipStream_t st, const char *what, int a_mode = TOAD_X_F32, int a_stride = 1, int y_stride = 1);
+                 unsigned long long *bits_out, hipStream_t st, const char *what, int a_mode = TOAD_X_F32, int a_stride = 1, int y_stride = 1,
+                 float *a_amax_out = nullptr, int *slab_ke = nullptr);   // a_amax == NULL + a_amax_out (zeroed) + slab_ke [256]: A is measured inside the GEMM
 size_t pt_bytes_host(int64_t rows, int64_t cols);                                                          // bytes of a plane-tiled tensor
 int launch_pt_split(const float *X, int64_t ld, int64_t M, int64_t K, const float *amax, unsigned short *pt, hipStream_t st, const char *what);
 int launch_pool_bwd(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *A_raw, const float *stats,

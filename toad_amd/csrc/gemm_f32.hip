@@ -77,6 +77,7 @@ static void cfg() {
 #undef TOAD_H2_ATTR
         TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 1>), H2_SMEM);
         TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 2>), H2_SMEM_PT);
+        TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 3>), H2_SMEM_RUN);
         TOAD_ATTR(gemm_tn_h2_big_kernel<false>, TN2_SMEM);
         TOAD_ATTR(gemm_tn_h2_big_kernel<true>, TN2_SMEM);
         TOAD_ATTR(gemm_tn_pt_kernel, TP_SMEM);
@@ -167,6 +168,11 @@ static bool narrow_ok(int64_t M, int64_t N, int64_t K, int64_t ldc, const float 
 bool h2_nt_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc) {
     return M >= 1 && K % BK == 0 && N % 4 == 0 && ldc % 4 == 0 && lda % 4 == 0 && (uint64_t)M * lda * 4 < (1ull << 32);
 }
+// the self-measuring operand mode keeps one bit per item of a workgroup: at most 64 items (M up to ~1 M rows at N = 512)
+bool nt_run_ok(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ((M + PB - 1) / PB) * ((N + PB - 1) / PB);
+    return h2_nt_ok(M, N, K, K, N) && (tiles + kNumXCD * PB_BLOCKS_PER_XCD - 1) / (kNumXCD * PB_BLOCKS_PER_XCD) + 2 <= 64;
+}
 size_t h2_planes_bytes(int64_t N, int64_t K) { return (size_t)((N + PB - 1) / PB) * PB * (size_t)K * 4; }   // two fp16 planes
 size_t h2_slab_bytes() { return (size_t)PB_GRID * PB * PB * sizeof(float); }
 size_t h2_binv_bytes(int64_t N) { return (size_t)((N + PB - 1) / PB) * PB * sizeof(float); }
@@ -210,19 +216,44 @@ int launch_pt_split(const float *X, int64_t ld, int64_t M, int64_t K, const floa
 int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C,
                         int64_t ldc, int64_t M, int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend,
                         const float *mask_src, const unsigned long long *mask_bits, H2Pool pool, float *slabs, float *y_amax,
-                        unsigned long long *bits_out, hipStream_t st, const char *what, int a_mode, int a_stride, int y_stride) {
+                        unsigned long long *bits_out, hipStream_t st, const char *what, int a_mode, int a_stride, int y_stride, float *a_amax_out,
+                        int *slab_ke) {
     const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
     (void)cfg();
+    // a_amax == NULL with a_amax_out (fp32 A, plain forward): the kernel measures A itself, stage by stage (AMODE 3, gemm_h2.inc), fills
+    // a_amax_out (zeroed by the caller) and slab_ke; the fix-up then reads the completed array
+    const bool run_mode = a_mode == TOAD_X_F32 && !a_amax && a_amax_out;
+    if (run_mode) {
+        if (addend || mask_src || mask_bits || pool.T > 0 || a_stride != 1 || !slab_ke) { set_error("%s: the self-measuring operand mode is a plain forward with per-block scales", what); return TOAD_EINVAL; }
+        hipLaunchKernelGGL((gemm_nt_h2_big_kernel<false, false, 0, 3>), dim3(PB_GRID), dim3(512), H2_SMEM_RUN, st, A, lda, (const float *)nullptr, planes,
+                           binv, C, ldc, (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, 0, slabs, y_amax, bits_out, tiles_m, tiles_n, a_stride, y_stride, a_amax_out, slab_ke);
+        int rcr = check_launch(what);
+        if (rcr) return rcr;
+        int max_rem = 0, rem_all = 0;
+        for (int x = 0; x < kNumXCD; ++x) { const NtPlan pl = nt_plan(x, tiles_m, tiles_n, (int)(K / BK)); if (pl.g > 1) { rem_all += pl.rem; if (pl.rem > max_rem) max_rem = pl.rem; } }
+        if (max_rem > 0) {
+            const H2Pool np{nullptr, nullptr, nullptr, 0};
+            if (rem_all > 8)
+                hipLaunchKernelGGL(nt_fixup_h2_kernel<4>, dim3(16, max_rem, kNumXCD), dim3(256), 0, st, (const float *)slabs, (const float *)a_amax_out, binv, C, ldc,
+                                   (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, np.a_raw, np.stats, np.dM, 0, y_amax, tiles_m, tiles_n, a_stride, y_stride, (const int *)slab_ke);
+            else
+                hipLaunchKernelGGL(nt_fixup_h2_kernel<1>, dim3(64, max_rem, kNumXCD), dim3(256), 0, st, (const float *)slabs, (const float *)a_amax_out, binv, C, ldc,
+                                   (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, np.a_raw, np.stats, np.dM, 0, y_amax, tiles_m, tiles_n, a_stride, y_stride, (const int *)slab_ke);
+            rcr = check_launch(what);
+        }
+        return rcr;
+    }
     if (a_mode != TOAD_X_F32) {   // A is fp16 [M, lda halves] or plane-tiled: plain forward only (no addend / mask / pooling variants are instantiated)
         if (addend || mask_src || mask_bits || pool.T > 0) { set_error("%s: the fp16 / plane-tiled operand kernels have no addend / mask / pooling epilogue", what); return TOAD_EINVAL; }
         if (a_mode == TOAD_X_PT)
             hipLaunchKernelGGL((gemm_nt_h2_big_kernel<false, false, 0, 2>), dim3(PB_GRID), dim3(512), H2_SMEM_PT, st, A, lda, a_amax, planes,
                                binv, C, ldc, (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
-                               (const float *)nullptr, (const float *)nullptr, 0, slabs, y_amax, bits_out, tiles_m, tiles_n, a_stride, y_stride);
+                               (const float *)nullptr, (const float *)nullptr, 0, slabs, y_amax, bits_out, tiles_m, tiles_n, a_stride, y_stride, (float *)nullptr, (int *)nullptr);
         else
         hipLaunchKernelGGL((gemm_nt_h2_big_kernel<false, false, 0, 1>), dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, (const float *)nullptr, planes,
                            binv, C, ldc, (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
-                           (const float *)nullptr, (const float *)nullptr, 0, slabs, y_amax, bits_out, tiles_m, tiles_n, a_stride, y_stride);
+                           (const float *)nullptr, (const float *)nullptr, 0, slabs, y_amax, bits_out, tiles_m, tiles_n, a_stride, y_stride, (float *)nullptr, (int *)nullptr);
         int rc16 = check_launch(what);
         if (rc16) return rc16;
         int max_rem16 = 0, rem_all16 = 0;
@@ -232,10 +263,10 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
             const float *fx_amax = a_mode == TOAD_X_PT ? a_amax : nullptr;
             if (rem_all16 > 8)
                 hipLaunchKernelGGL(nt_fixup_h2_kernel<4>, dim3(16, max_rem16, kNumXCD), dim3(256), 0, st, (const float *)slabs, fx_amax, binv, C, ldc,
-                                   (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, np.a_raw, np.stats, np.dM, 0, y_amax, tiles_m, tiles_n, a_stride, y_stride);
+                                   (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, np.a_raw, np.stats, np.dM, 0, y_amax, tiles_m, tiles_n, a_stride, y_stride, (const int *)nullptr);
             else
                 hipLaunchKernelGGL(nt_fixup_h2_kernel<1>, dim3(64, max_rem16, kNumXCD), dim3(256), 0, st, (const float *)slabs, fx_amax, binv, C, ldc,
-                                   (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, np.a_raw, np.stats, np.dM, 0, y_amax, tiles_m, tiles_n, a_stride, y_stride);
+                                   (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, np.a_raw, np.stats, np.dM, 0, y_amax, tiles_m, tiles_n, a_stride, y_stride, (const int *)nullptr);
             rc16 = check_launch(what);
         }
         return rc16;
@@ -245,7 +276,7 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
     const float *msrc = mask_bits ? reinterpret_cast<const float *>(mask_bits) : mask_src;
 #define TOAD_LAUNCH_H2(P, A_, M_)                                                                                                     \
     hipLaunchKernelGGL((gemm_nt_h2_big_kernel<P, A_, M_>), dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, a_amax, planes, binv, C, ldc, (int)M, \
-                       (int)N, (int)K, bias, es, addend, msrc, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, bits_out, tiles_m, tiles_n, a_stride, y_stride)
+                       (int)N, (int)K, bias, es, addend, msrc, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, bits_out, tiles_m, tiles_n, a_stride, y_stride, (float *)nullptr, (int *)nullptr)
     const int msk = mask_bits ? 2 : (mask_src ? 1 : 0);
     if (mask_bits && !mask_src) { set_error("%s: the one-bit ReLU image needs the fp32 relu_src as well (remainder tiles)", what); return TOAD_EINVAL; }
     if (pool.T > 0) { if (msk == 2) TOAD_LAUNCH_H2(true, false, 2); else if (msk == 1) TOAD_LAUNCH_H2(true, false, 1); else TOAD_LAUNCH_H2(true, false, 0); }
@@ -261,10 +292,10 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
         for (int x = 0; x < kNumXCD; ++x) { const NtPlan pl = nt_plan(x, tiles_m, tiles_n, (int)(K / BK)); if (pl.g > 1) rem_all += pl.rem; }
         if (rem_all > 8)
             hipLaunchKernelGGL(nt_fixup_h2_kernel<4>, dim3(16, max_rem, kNumXCD), dim3(256), 0, st, (const float *)slabs, a_amax, binv, C, ldc,
-                               (int)M, (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, y_amax, tiles_m, tiles_n, a_stride, y_stride);
+                               (int)M, (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, y_amax, tiles_m, tiles_n, a_stride, y_stride, (const int *)nullptr);
         else
             hipLaunchKernelGGL(nt_fixup_h2_kernel<1>, dim3(64, max_rem, kNumXCD), dim3(256), 0, st, (const float *)slabs, a_amax, binv, C, ldc,
-                               (int)M, (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, y_amax, tiles_m, tiles_n, a_stride, y_stride);
+                               (int)M, (int)N, (int)K, bias, es, addend, mask_src, pool.a_raw, pool.stats, pool.dM, pool.T, y_amax, tiles_m, tiles_n, a_stride, y_stride, (const int *)nullptr);
         rc = check_launch(what);
     }
     return rc;
@@ -293,11 +324,20 @@ static int launch_nt_auto(const float *A, int64_t lda, const float *a_amax, cons
         float *binv = reinterpret_cast<float *>(w);
         w += h2_binv_bytes(N);
         float *amax_ws = reinterpret_cast<float *>(w);
-        if (!a_amax) {
+        int *slab_ke = reinterpret_cast<int *>(amax_ws + h2_nblk(M) + 64);
+        // A without an abs-max array: a plain forward measures it inside the GEMM (AMODE 3, like the whole-slide calls: the two routes stay
+        // bitwise equal); a product with an addend / mask / pooling epilogue measures it with a pass of its own
+        const bool self_measure = !a_amax && !addend && !mask_src && !mask_bits && pool.T == 0 && nt_run_ok(M, N, K);
+        if (!a_amax && !self_measure) {
             if (int rc = launch_absmax(A, lda, M, K, amax_ws, true, st, what)) return rc;
             a_amax = amax_ws;
         }
         const H2Operand op{B, ldb, 1, N, K, planes, binv};
+        if (self_measure) {
+            if (int rc = launch_split_h2(&op, 1, amax_ws, (int)h2_nblk(M), st, what)) return rc;      // (the split launch zeroes the array the GEMM fills)
+            return launch_nt_h2(A, lda, nullptr, planes, binv, C, ldc, M, N, K, bias, es, nullptr, nullptr, nullptr, pool, slabs, y_amax, bits_out, st, what,
+                                TOAD_X_F32, 1, 1, amax_ws, slab_ke);
+        }
         if (int rc = launch_split_h2(&op, 1, nullptr, 0, st, what)) return rc;
         return launch_nt_h2(A, lda, a_amax, planes, binv, C, ldc, M, N, K, bias, es, addend, mask_src, mask_bits, pool, slabs, y_amax, bits_out, st, what);
     }
@@ -369,7 +409,7 @@ extern "C" size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K) {
     const size_t tiles_n = (size_t)((N + PB - 1) / PB), kpad = (size_t)((K + 2 * BK - 1) / (2 * BK) * (2 * BK));
     // (the h2 path needs 4 bytes per weight element + inverse scales + the abs-max array of A; the 6-byte planes of the older split cover it)
     return (size_t)PB_GRID * PB * PB * sizeof(float) + tiles_n * PB * kpad * 6 + tiles_n * PB * sizeof(float) +
-           (size_t)(h2_nblk(M > 0 ? M : 1) + 64) * sizeof(float) + 256;
+           (size_t)(h2_nblk(M > 0 ? M : 1) + 64) * sizeof(float) + 256 + PB_GRID * sizeof(int);     // ... + the K-slice exponents of a self-measured operand
 }
 
 extern "C" int toad_linear_h2_ok(int64_t M, int64_t N, int64_t K) { return h2_nt_ok(M, N, K, K, N) ? 1 : 0; }

@@ -63,6 +63,7 @@ struct Scratch {
     void *pool_ws, *poolb_ws; size_t pool_ws_bytes, poolb_ws_bytes;
     float *dlogits, *dsite, *dM, *loss;
     float *amax_dP, *amax_dZ2, *amax_dZ1;
+    int *slab_ke;                                             // exponents of the first Linear's K-split slabs (the GEMM measures a raw fp32 bag itself)
     float *dP, *dZ2, *dZ1;
     void *wgrad_ws, *wgrad_ws2, *wgrad_ws3; size_t wgrad_ws_bytes;
     size_t total;
@@ -96,6 +97,7 @@ static Scratch scratch_layout(const MilShape &s, char *base) {
     r.amax_dP = reinterpret_cast<float *>(P(c.take(nb, 256)));        // three adjacent arrays: one memset per backward
     r.amax_dZ2 = reinterpret_cast<float *>(P(c.take(nb, 4)));
     r.amax_dZ1 = reinterpret_cast<float *>(P(c.take(nb, 4)));
+    r.slab_ke = reinterpret_cast<int *>(P(c.take(256 * sizeof(int), 256)));
     r.dP = reinterpret_cast<float *>(P(c.take(N * D2 * 4, big)));
     r.dZ2 = reinterpret_cast<float *>(P(c.take(N * kL * 4, big)));
     r.dZ1 = reinterpret_cast<float *>(P(c.take(N * kL * 4, big)));
@@ -176,10 +178,13 @@ static int forward_body(const MilShape &s, const Params &p, const float *X, cons
         }
         // an fp16 bag needs no abs-max array: its elements are first pieces with scale 1 (gemm_nt_h2_big_kernel, A16)
         const float *ax = x_mode == TOAD_X_PT ? x_amax : f.amax_x;    // a prepared bag carries its own array: nothing to copy or measure
-        if (x_mode != TOAD_X_F32) {}
-        else if (x_amax) (void)hipMemcpyAsync(f.amax_x, x_amax, toad_amax_floats(N) * sizeof(float), hipMemcpyDeviceToDevice, st);
-        else TOAD_TRY(launch_absmax(X, kL0, N, kL0, f.amax_x, false, st, what));
-        ev(2); TOAD_TRY(launch_nt_h2(X, kL0, ax, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h1, f.bits_h1, st, what, x_mode)); ev(3);
+        // a raw fp32 bag without an abs-max array is measured INSIDE the first GEMM (running block maximum, gemm_h2.inc AMODE 3), which fills
+        // f.amax_x (zeroed by the split launch above) for the weight gradient of this layer: no pass over the bag of its own
+        const bool self_measure = x_mode == TOAD_X_F32 && !x_amax && nt_run_ok(N, kL, kL0);
+        if (x_mode == TOAD_X_F32 && !x_amax && !self_measure) TOAD_TRY(launch_absmax(X, kL0, N, kL0, f.amax_x, false, st, what));
+        if (x_mode == TOAD_X_F32 && x_amax) (void)hipMemcpyAsync(f.amax_x, x_amax, toad_amax_floats(N) * sizeof(float), hipMemcpyDeviceToDevice, st);
+        ev(2); TOAD_TRY(launch_nt_h2(X, kL0, self_measure ? nullptr : ax, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool,
+                                     w.slabs, f.amax_h1, f.bits_h1, st, what, x_mode, 1, 1, self_measure ? f.amax_x : nullptr, self_measure ? w.slab_ke : nullptr)); ev(3);
         ev(4); TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h, f.bits_h, st, what)); ev(5);
         ev(6); TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nullptr, nopool, w.slabs, nullptr, nullptr, st, what)); ev(7);
     } else {       // shapes beyond the persistent kernels' 32-bit offsets (> 1 M patches): the per-op entry points pick their kernels
@@ -538,8 +543,11 @@ extern "C" int toad_mil_multi_step_f32(const float *const *params, float *const 
         const int nzb = (int)(((char *)w.amax_dZ1 - (char *)w.amax_dP) / sizeof(float) + toad_amax_floats(N));
         TOAD_TRY(launch_split_h2(ops5, 5, f.amax_x, nz, st, what, w.amax_dP, nzb));
     }
-    TOAD_TRY(launch_absmax(Xcat, kL0, N, kL0, f.amax_x, false, st, what));
-    ev(2); TOAD_TRY(launch_nt_h2(Xcat, kL0, f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h1, f.bits_h1, st, what)); ev(3);
+    // the concatenated bags are measured inside the first GEMM (no abs-max pass of its own), which fills f.amax_x for the weight gradient below
+    const bool self_measure = nt_run_ok(N, kL, kL0);
+    if (!self_measure) TOAD_TRY(launch_absmax(Xcat, kL0, N, kL0, f.amax_x, false, st, what));
+    ev(2); TOAD_TRY(launch_nt_h2(Xcat, kL0, self_measure ? nullptr : f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool,
+                                 w.slabs, f.amax_h1, f.bits_h1, st, what, TOAD_X_F32, 1, 1, self_measure ? f.amax_x : nullptr, self_measure ? w.slab_ke : nullptr)); ev(3);
     ev(4); TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h, nullptr, st, what)); ev(5);
     ev(6); TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nullptr, nopool, w.slabs, nullptr, nullptr, st, what)); ev(7);
     // ---- all slides at once (blockIdx.y = slide): fused pool forward on each row range + merge; heads + weighted CE + heads backward with

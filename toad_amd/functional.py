@@ -68,9 +68,11 @@ def trunk_scores(w: Dict[str, torch.Tensor], x: torch.Tensor, drop_p: float = 0.
     """models/model_toad.py:59-64 trunk (+Dropout when training with dropout=True) + :21,:25 stacked
     attention pre-activations. Returns (h1, h, p, (x_amax, h1_amax, h_amax, h1_bits, h_bits))."""
     s1, s2, _, _ = drop_seeds(seed)
+    # a bag without an abs-max array is measured inside the first GEMM (as in the whole-slide calls: the two routes stay bitwise equal); the
+    # array itself - the weight gradient of this layer scales the bag with its maximum - is taken by a pass of its own on this per-op route
+    h1, h1_amax, h1_bits = ops.linear_act_fwd(x, w["w1"], w["b1"], ops.ACT_RELU, drop_p=drop_p, drop_seed=s1, x_amax=x_amax, want_bits=True)
     if x_amax is None:
         x_amax = ops.absmax_rows256(x)
-    h1, h1_amax, h1_bits = ops.linear_act_fwd(x, w["w1"], w["b1"], ops.ACT_RELU, drop_p=drop_p, drop_seed=s1, x_amax=x_amax, want_bits=True)
     h, h_amax, h_bits = ops.linear_act_fwd(h1, w["w2"], w["b2"], ops.ACT_RELU, drop_p=drop_p, drop_seed=s2, x_amax=h1_amax, want_bits=True)
     wab, bab = _stack_ab(w)
     p = ops.linear_act_fwd(h, wab, bab, ops.ACT_NONE, x_amax=h_amax)
