@@ -105,7 +105,7 @@ def _cpu_name() -> str:
     return "unknown"
 
 
-POOL_TRAFFIC_FILE = "r03_pool_traffic.json"     # re-measured whenever the pool kernels change (tools/pmc_pool_traffic.sh writes it)
+POOL_TRAFFIC_FILE = "r04_pool_traffic.json"     # re-measured whenever the pool kernels change (tools/pmc_pool_traffic.sh writes it)
 
 
 def measured_pool_traffic(n: int):

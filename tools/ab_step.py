@@ -16,7 +16,7 @@ slides = []
 for b in range(2):
     g = torch.Generator(device=dev).manual_seed(1000 + b)
     slides.append((torch.randn(n, 1024, device=dev, generator=g), torch.tensor([1.0], device=dev), torch.tensor([3], device=dev), torch.tensor([1], device=dev)))
-if os.environ.get("TOAD_BAG", "prepared") == "prepared":         # the ingest format (ops.prepare_bag); TOAD_BAG=fp32 for the fp32 bag
+if os.environ.get("TOAD_BAG", "fp32") == "prepared":         # the ingest format (ops.prepare_bag); TOAD_BAG=fp32 for the fp32 bag
     slides = [(ops.prepare_bag(s[0]),) + s[1:] for s in slides]
 for i in range(5):
     dp.step([slides[i % 2]], 1)
@@ -35,5 +35,5 @@ def mean(lst): return sum(a.elapsed_time(b) for a, b in lst) / len(lst) * 1e3
 f, w, d = T["gemm_fwd"], T["gemm_wgrad"], T["gemm_dgrad"]
 row = {"fwd1": mean(f[0::3]), "fwd2": mean(f[1::3]), "fwd_ab": mean(f[2::3]), "wgrad_ab": mean(w[0::3]), "dgrad_ab": mean(d[0::2]),
        "wgrad2": mean(w[1::3]), "dgrad2": mean(d[1::2]), "wgrad1": mean(w[2::3]), "pool_fwd": mean(T["pool_fwd"])}
-tag = (os.path.basename(os.environ.get("TOAD_HIP_LIB", "libtoad_hip.so")).replace("libtoad_hip", "").replace(".so", "") or "(shipped)") + "/" + os.environ.get("TOAD_BAG", "prepared")
+tag = (os.path.basename(os.environ.get("TOAD_HIP_LIB", "libtoad_hip.so")).replace("libtoad_hip", "").replace(".so", "") or "(shipped)") + "/" + os.environ.get("TOAD_BAG", "fp32")
 print(f"{tag:20s} step {plain:6.3f} ms | " + " ".join(f"{k} {v:6.1f}" for k, v in row.items()) + f" | gemm sum {sum(v for k, v in row.items() if k != 'pool_fwd'):7.1f}", flush=True)

@@ -27,7 +27,7 @@ for what in "$@"; do
       for r in 1 2; do for b in prepared fp32; do TOAD_BAG=$b timeout 300 python tools/ab_step.py ${arg:-100000} 30; done; done 2>&1 | grep -v amdgpu.ids | tee $OUT/ab.txt ;;
     stats)
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python $ROOT/tools/pmc_step.py ${arg:-100000} 8 > $OUT/prof.log 2>&1)
-      python tools/summarize_rocprof.py $(find $OUT/prof -name "*kernel_stats.csv" | head -1) "$TAG fused step N=${arg:-100000} (8 steps, prepared bag)" > $OUT/kernel_stats.md 2>&1
+      python tools/summarize_rocprof.py $(find $OUT/prof -name "*kernel_stats.csv" | head -1) "$TAG fused step N=${arg:-100000} (8 steps, raw fp32 bag)" > $OUT/kernel_stats.md 2>&1
       head -24 $OUT/kernel_stats.md ;;
     bstats)         # rocprofv3 --kernel-trace --stats of the bench command itself (the summary the bench line's kernel times are checked against)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bprof -o p -- python $ROOT/bench.py ${arg:---steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0} > $OUT/bprof.json 2> $OUT/bprof.err)

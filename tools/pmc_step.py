@@ -15,7 +15,7 @@ model = TOAD_fc_mtl_concat(n_classes=18); model.relocate(); model.train()
 dp = SlideShardedDP(model, {"lr": 1e-4, "weight_decay": 1e-5})
 g = torch.Generator(device=dev).manual_seed(1000)
 slide = (torch.randn(n, 1024, device=dev, generator=g), torch.tensor([1.0], device=dev), torch.tensor([3], device=dev), torch.tensor([1], device=dev))
-if os.environ.get("TOAD_BAG", "prepared") == "prepared":
+if os.environ.get("TOAD_BAG", "fp32") == "prepared":
     from toad_amd import ops
     slide = (ops.prepare_bag(slide[0]),) + slide[1:]
 for _ in range(steps):
