@@ -101,7 +101,7 @@ enum { TOAD_X_F32 = 0,      // fp32 [N][1024]
 // ---- host-side launchers of the fp16 two-piece GEMMs (defined in gemm_f32.hip next to their kernels; used by step.hip) ----
 struct H2Operand { const float *src; int64_t sn, sk; int64_t N, K; unsigned short *planes; float *binv; };   // B[n,k] = src[n*sn + k*sk]
 struct H2Pool { const float *a_raw, *stats, *dM; int T; };                                                   // recomputed pooling addend (T = 0: none)
-struct EpiScalars { int relu; float mask_scale; DropArgs drop; };                                            // epilogue scalars of every NT kernel
+struct EpiScalars { int relu; float mask_scale; DropArgs drop; int stagger = 0; };                           // epilogue scalars of every NT kernel; stagger: gemm_h2.inc
 bool h2_nt_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc);
 bool nt_run_ok(int64_t M, int64_t N, int64_t K);       // the first GEMM may measure its fp32 A operand itself (gemm_h2.inc AMODE 3)
 size_t h2_planes_bytes(int64_t N, int64_t K);

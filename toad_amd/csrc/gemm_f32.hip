@@ -491,6 +491,10 @@ int toad::ext_linear(const float *X, const float *x_gmax, const float *W, const 
         float *binv = reinterpret_cast<float *>(w);
         const H2Operand op{W, K, 1, N, K, planes, binv};
         if (int rc = launch_split_h2(&op, 1, nullptr, 0, st, what)) return rc;
+        // short reductions: a tile is a few k-steps of matrix work followed by 256-512 KB of epilogue traffic, and 256 workgroups in phase make
+        // the GEMM the SUM of the two. Spread the starts over one expected tile period (10 ns ticks: ~1.95 us per k-step, ~8 us per 256 KB of
+        // epilogue traffic; measured on the extractor's shapes, tools/ab/duo_ext_bench.py: -8..-10 % on the residual GEMMs, neutral from K = 1024)
+        if (K <= 512 && M >= 32 * 1024) es.stagger = (int)std::min<int64_t>((K / BK) * 195 + (residual ? 1600 : 800), 3000);
         return launch_nt_h2(X, K, x_gmax, planes, binv, Y, N, M, N, K, bias, es, residual, nullptr, nullptr, H2Pool{nullptr, nullptr, nullptr, 0}, slabs,
                             y_gmax, nullptr, st, what, TOAD_X_F32, 0, 0);
     }

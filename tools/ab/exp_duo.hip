@@ -35,3 +35,26 @@ extern "C" int toad_exp_nt_duo_f32(const float *X, const float *W, int64_t wsn, 
                             reinterpret_cast<const unsigned long long *>(relu_bits_in), H2Pool{pool_a_raw, pool_stats, pool_dM, pool_T}, y_amax,
                             reinterpret_cast<unsigned long long *>(relu_bits_out), st, what, trace);
 }
+
+// The extractor's wide GEMM (ext_linear's "big" branch: tensor-wide scalar scales, optional residual) on the shipped 8-wave kernel (which = 0)
+// or on the duo kernel (which = 1). x_gmax: device scalar max |X| (given); y_gmax: device scalar receiving max |Y| (zeroed by the caller) or NULL.
+extern "C" int toad_exp_ext_f32(int which, const float *X, const float *x_gmax, const float *W, const float *bias, const float *residual, float *Y, float *y_gmax,
+                                int64_t M, int64_t K, int64_t N, int act, void *ws, size_t ws_bytes, void *stream) {
+    const char *what = "toad_exp_ext_f32";
+    hipStream_t st = (hipStream_t)stream;
+    if (ws_bytes < toad_linear_ws_bytes(M, N, K) || !h2_nt_ok(M, N, K, K, N)) { set_error("%s: workspace / shape", what); return TOAD_ESHAPE; }
+    char *w = reinterpret_cast<char *>(ws);
+    float *slabs = reinterpret_cast<float *>(w);
+    w += (size_t)PB_GRID * PB * PB * sizeof(float);
+    unsigned short *planes = reinterpret_cast<unsigned short *>(w);
+    w += h2_planes_bytes(N, K);
+    float *binv = reinterpret_cast<float *>(w);
+    const H2Operand op{W, K, 1, N, K, planes, binv};
+    if (int rc = launch_split_h2(&op, 1, nullptr, 0, st, what)) return rc;
+    EpiScalars es{act == TOAD_ACT_RELU, 1.f, make_drop(0.f, 0)};
+    const H2Pool nopool{nullptr, nullptr, nullptr, 0};
+    if (which >= 2) es.stagger = which;              // which >= 2: the shipped kernel with a staggered start, which = the period in 10 ns ticks
+    if (which == 0 || which >= 2)
+        return launch_nt_h2(X, K, x_gmax, planes, binv, Y, N, M, N, K, bias, es, residual, nullptr, nullptr, nopool, slabs, y_gmax, nullptr, st, what, TOAD_X_F32, 0, 0);
+    return launch_nt_h2_duo(X, K, x_gmax, planes, binv, Y, N, M, N, K, bias, es, residual, nullptr, nullptr, nopool, y_gmax, nullptr, st, what, nullptr, 0, 0);
+}
