@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOAD_ABI_VERSION 10
+#define TOAD_ABI_VERSION 11
 
 enum { TOAD_OK = 0, TOAD_EINVAL = -1, TOAD_ESHAPE = -2, TOAD_EWORKSPACE = -3, TOAD_EALIGN = -4 };
 enum { TOAD_ACT_NONE = 0, TOAD_ACT_RELU = 1 };
@@ -247,6 +247,11 @@ int toad_im2col_stem_nchw_f32(const float *X, float *cols, int B, int H, int W, 
 int toad_stem_s2d_nchw_f32(const float *X, float *Xs, int B, int H, int W, void *stream);
 int toad_stem_conv_s2d_f32(const float *Xs, const float *Wf, const float *bias, float *Y, int B, int Ho, int Wo, int act,
                            void *ws, size_t ws_bytes, void *stream);
+/* The stem + folded BN + ReLU AND the 3x3/2 max-pool that follows it (models/resnet_custom.py:96-99) as ONE kernel: the pool is formed in the
+ * GEMM's epilogue, the stem's own output is never stored. Yp is NHWC [B, Ho/2, Wo/2, 64], bit-identical to toad_maxpool3x3s2_nhwc_f32 of
+ * toad_stem_conv_s2d_f32(.., TOAD_ACT_RELU). Shapes: Wo == 128 (tiles 256 wide) and Ho even; TOAD_ESHAPE otherwise. */
+int toad_stem_conv_pool_s2d_f32(const float *Xs, const float *Wf, const float *bias, float *Yp, int B, int Ho, int Wo,
+                                void *ws, size_t ws_bytes, void *stream);
 
 /* nn.MaxPool2d(kernel 3, stride 2, padding 1) (:66) on NHWC; C % 4 == 0. Y is [B, Ho, Wo, C]. */
 int toad_maxpool3x3s2_nhwc_f32(const float *X, float *Y, int B, int H, int W, int C, void *stream);

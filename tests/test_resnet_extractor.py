@@ -122,6 +122,27 @@ def test_stem_gather_maxpool_avgpool_bit_exact(cuda, b, h, w):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,h,w", [(1, 256, 256), (3, 256, 256), (5, 64, 256), (37, 128, 256), (7, 4, 256), (2, 12, 256), (40, 256, 256)])
+def test_stem_with_the_maxpool_in_its_epilogue_is_bitwise_the_two_kernel_path(cuda, b, h, w):
+    """models/resnet_custom.py:96-99 as ONE kernel (gemm_stream.inc, GATHER_STEM_POOL): contiguous tile ranges per workgroup, carried pooled rows, image
+    tops inside and at the start of a range, left edges, fewer / more tiles than workgroups - every value must equal max_pool(relu(stem))."""
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(b * 1000 + h)
+    x = (torch.randn(b, 3, h, w, generator=g) * torch.rand(b, 1, 1, 1, generator=g).mul(3).exp()).to(cuda)     # images of different brightness
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    bias = torch.randn(64, generator=g)
+    w8 = torch.zeros(64, 3, 8, 8); w8[:, :, 1:, 1:] = wt
+    wf = w8.view(64, 3, 4, 2, 4, 2).permute(0, 2, 4, 3, 5, 1).reshape(64, 192).contiguous().to(cuda)
+    two = ops.maxpool3x3s2_nhwc(ops.stem_conv(x, wf, bias.to(cuda), 1))
+    one = ops.stem_conv_pool(x, wf, bias.to(cuda))
+    assert one.shape == two.shape == (b, h // 4, w // 4, 64)
+    assert torch.equal(one, two), f"max abs diff {(one - two).abs().max().item():.3e} at {(one != two).nonzero()[:3].tolist()}"
+    assert torch.equal(one, ops.stem_conv_pool(x, wf, bias.to(cuda)))
+    with pytest.raises(RuntimeError, match="pooled stem"):
+        ops.stem_conv_pool(x[:, :, :, :128].contiguous(), wf, bias.to(cuda))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("m,k,n,res,act", [(4096, 64, 64, False, 1), (1000, 576, 64, False, 1), (777, 128, 512, True, 1),
                                            (2048, 2304, 256, False, 1), (300, 160, 64, False, 1), (512, 256, 1024, True, 0),
                                            # streamed kernels with more tiles than workgroups (cross-tile prefetch, one weight chunk per tile), ragged M

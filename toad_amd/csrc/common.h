@@ -129,7 +129,8 @@ int ext_conv_nhwc(const float *X, const float *x_gmax, const float *Wf, const fl
                   int H, int W, int Cin, int kh, int kw, int stride, int pad, int Cout, int act, void *ws, size_t ws_bytes, hipStream_t st,
                   const char *what);
 int ext_stem_conv(const float *Xs, const float *x_gmax, const float *Wf, const float *bias, float *Y, float *y_gmax, int B, int Ho, int Wo, int act,
-                  void *ws, size_t ws_bytes, hipStream_t st, const char *what);
+                  void *ws, size_t ws_bytes, hipStream_t st, const char *what, bool pooled = false);
+bool stem_pool_ok(int Ho, int Wo, int act);           // the stem may take the 3x3/2 max-pool into its epilogue (gemm_stream.inc)
 // batched pooling launches of the ragged multi-slide step (gated_pool.hip): blockIdx.y = slide, row ranges from the DEVICE array seg_dev [B+1]
 size_t pool_batch_ws_bytes(int B, int L, int D, int T);
 int launch_pool_fwd_batch(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *bc, float *A_raw, float *M,

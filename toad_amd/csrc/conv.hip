@@ -300,8 +300,12 @@ extern "C" int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float 
     hipLaunchKernelGGL(stem_s2d_kernel, dim3(grid_for((uint64_t)B * (p.Hs + 3) * (p.Ws + 3))), dim3(256), 0, st, tiles_nchw, cols, B, H, W, p.Hs + 3, p.Ws + 3, g_in);
     TOAD_TRY(check_launch(what));
     float *gx = slot();
-    TOAD_TRY(ext_stem_conv(cols, g_in, weights[0], biases[0], act[0], gx, B, p.Hs, p.Ws, TOAD_ACT_RELU, gws, gcap, st, what));
-    TOAD_TRY(toad_maxpool3x3s2_nhwc_f32(act[0], act[1], B, p.Hs, p.Ws, 64, st));      // max-pooling keeps the maximum: same slot
+    if (stem_pool_ok(p.Hs, p.Ws, TOAD_ACT_RELU)) {      // tiles 256 wide: the max-pool rides in the stem's epilogue, the stem's own output is never stored
+        TOAD_TRY(ext_stem_conv(cols, g_in, weights[0], biases[0], act[1], gx, B, p.Hs, p.Ws, TOAD_ACT_RELU, gws, gcap, st, what, true));
+    } else {
+        TOAD_TRY(ext_stem_conv(cols, g_in, weights[0], biases[0], act[0], gx, B, p.Hs, p.Ws, TOAD_ACT_RELU, gws, gcap, st, what));
+        TOAD_TRY(toad_maxpool3x3s2_nhwc_f32(act[0], act[1], B, p.Hs, p.Ws, 64, st));      // max-pooling keeps the maximum: same slot
+    }
     float *x = act[1];                          // block input (abs-max scalar: gx)
     auto other = [&](float *a0, float *a1, float *a2) {          // a buffer different from the (up to) three in use
         for (int i = 0; i < 4; ++i) if (act[i] != a0 && act[i] != a1 && act[i] != a2) return act[i];

@@ -88,6 +88,7 @@ static void cfg() {
         TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 2, GATHER_CONV>), (StreamCfg<2, 2>::SMEM));
         TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 4, GATHER_CONV>), (StreamCfg<2, 4>::SMEM));
         TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 2, GATHER_STEM>), (StreamCfg<2, 2>::SMEM));
+        TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 2, GATHER_STEM_POOL>), (StreamCfg<2, 2>::SMEM + STEM_POOL_LDS));
         TOAD_ATTR(conv3x3_h2_halo_kernel<2>, 160 * 1024);
         TOAD_ATTR(conv3x3_h2_halo_kernel<4>, 160 * 1024);
 #undef TOAD_ATTR
@@ -152,6 +153,11 @@ static int launch_narrow_t(const float *A, int64_t lda, const float *a_gmax, con
     constexpr int SRA = 2;
     using SCfg = StreamCfg<SRA, NB>;
     const int stiles_m = (int)((M + SCfg::TM - 1) / SCfg::TM);
+    if constexpr (MODE == GATHER_STEM_POOL) {        // C = the POOLED output; every workgroup a contiguous range of row-pair tiles (ext_stem_conv checked the geometry)
+        hipLaunchKernelGGL((gemm_nt_h2_stream_kernel<SRA, NB, MODE>), dim3(std::min(stiles_m, SCfg::WG_PER_CU * PB_GRID)), dim3(SCfg::THREADS), SCfg::SMEM + STEM_POOL_LDS, st,
+                           A, lda, a_gmax, planes, binv, C, ldc, (int)M, (int)N, (int)K, bias, relu, addend, cg, y_gmax, stiles_m, tiles_n);
+        return check_launch(what);
+    }
     hipLaunchKernelGGL((gemm_nt_h2_stream_kernel<SRA, NB, MODE>), dim3(SCfg::WG_PER_CU * PB_GRID), dim3(SCfg::THREADS), SCfg::SMEM, st, A, lda, a_gmax, planes, binv,
                        C, ldc, (int)M, (int)N, (int)K, bias, relu, addend, cg, y_gmax, stiles_m, tiles_n);
     return check_launch(what);
@@ -540,7 +546,7 @@ extern "C" int toad_conv_nhwc_f32(const float *X, const float *Wf, const float *
 }
 
 int toad::ext_stem_conv(const float *Xs, const float *x_gmax, const float *Wf, const float *bias, float *Y, float *y_gmax, int B, int Ho, int Wo, int act,
-                        void *ws, size_t ws_bytes, hipStream_t st, const char *what) {
+                        void *ws, size_t ws_bytes, hipStream_t st, const char *what, bool pooled) {
     if (!Xs || !Wf || !Y || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (act != TOAD_ACT_NONE && act != TOAD_ACT_RELU) { set_error("%s: bad act %d", what, act); return TOAD_EINVAL; }
     if (B <= 0 || Ho <= 0 || Wo <= 0) { set_error("%s: bad geometry", what); return TOAD_ESHAPE; }
@@ -556,11 +562,23 @@ int toad::ext_stem_conv(const float *Xs, const float *x_gmax, const float *Wf, c
         x_gmax = g;
     }
     const ConvGeom cg{Hs, Ws, 12, Ho, Wo, 0, 0, 0};
+    if (pooled) {
+        // the 3x3/2 max-pool in the stem's epilogue (gemm_stream.inc): a tile = two whole image rows, ReLU outputs
+        if (!stem_pool_ok(Ho, Wo, act)) { set_error("%s: the pooled stem needs Wo = 128, an even Ho and ReLU", what); return TOAD_ESHAPE; }
+        return launch_narrow_t<2, 2, GATHER_STEM_POOL>(Xs, 0, x_gmax, Wf, 192, Y, 64, M, 64, 192, bias, 1, nullptr, cg, y_gmax, ws, st, what);
+    }
     return launch_narrow_t<2, 2, GATHER_STEM>(Xs, 0, x_gmax, Wf, 192, Y, 64, M, 64, 192, bias, act == TOAD_ACT_RELU, nullptr, cg, y_gmax, ws, st, what);
 }
+bool toad::stem_pool_ok(int Ho, int Wo, int act) { return Wo == 128 && Ho > 0 && Ho % 2 == 0 && act == TOAD_ACT_RELU; }
 extern "C" int toad_stem_conv_s2d_f32(const float *Xs, const float *Wf, const float *bias, float *Y, int B, int Ho, int Wo, int act,
                                       void *ws, size_t ws_bytes, void *stream) {
     return ext_stem_conv(Xs, nullptr, Wf, bias, Y, nullptr, B, Ho, Wo, act, ws, ws_bytes, (hipStream_t)stream, "toad_stem_conv_s2d_f32");
+}
+// The stem AND nn.MaxPool2d(3, 2, 1) as one kernel (models/resnet_custom.py:96-99): Yp [B, Ho/2, Wo/2, 64]. Shapes: Wo = 128, Ho a multiple of 32
+// (256 x 256 tiles); others take toad_stem_conv_s2d_f32 + toad_maxpool3x3s2_nhwc_f32.
+extern "C" int toad_stem_conv_pool_s2d_f32(const float *Xs, const float *Wf, const float *bias, float *Yp, int B, int Ho, int Wo, void *ws, size_t ws_bytes,
+                                           void *stream) {
+    return ext_stem_conv(Xs, nullptr, Wf, bias, Yp, nullptr, B, Ho, Wo, TOAD_ACT_RELU, ws, ws_bytes, (hipStream_t)stream, "toad_stem_conv_pool_s2d_f32", true);
 }
 
 extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend, const float *relu_src,

@@ -759,6 +759,23 @@ def stem_conv(x: torch.Tensor, wf: torch.Tensor, b, act: int) -> torch.Tensor:
     return y
 
 
+def stem_conv_pool(x: torch.Tensor, wf: torch.Tensor, b) -> torch.Tensor:
+    """Stem + ReLU + 3x3/2 max-pool as one kernel (tiles 256 wide: Wo == 128, Ho even): x [B,3,H,W] -> [B,Ho/2,Wo/2,64] NHWC,
+    bit-identical to maxpool3x3s2_nhwc(stem_conv(x, wf, b, ACT_RELU))."""
+    _chk(x, "x"); _chk(wf, "wf"); _chk(b, "b", allow_none=True)
+    bb, c, h, w = x.shape
+    if c != 3 or tuple(wf.shape) != (64, 192):
+        raise ValueError("stem_conv_pool: expected [B,3,H,W] tiles and a [64,192] space-to-depth weight")
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    xs = torch.empty((bb, ho + 3, wo + 3, 12), dtype=torch.float32, device=x.device)
+    y = torch.empty((bb, ho // 2, wo // 2, 64), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.toad_stem_s2d_nchw_f32(_p(x), _p(xs), bb, h, w, _stream()), "toad_stem_s2d_nchw_f32")
+    ws = _ws(lib.toad_linear_ws_bytes(bb * ho * wo, 64, 192), x.device)
+    _lib.check(lib.toad_stem_conv_pool_s2d_f32(_p(xs), _p(wf), _p(b), _p(y), bb, ho, wo, _p(ws), ws.numel(), _stream()), "toad_stem_conv_pool_s2d_f32")
+    return y
+
+
 def maxpool3x3s2_nhwc(x: torch.Tensor) -> torch.Tensor:
     _chk(x, "x")
     b, h, w, c = x.shape

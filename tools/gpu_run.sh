@@ -4,6 +4,7 @@
 #   ab:N          tools/ab_step.py on prepared and fp32 bags                         stats[:N]     rocprofv3 --kernel-trace --stats of the fused step
 #   pmc[:N]       SQ counter pass of the fused step                                  smoke         __graft_entry__.smoke()
 #   traffic[:N]   FETCH_SIZE / WRITE_SIZE passes of the pool kernels -> pool_traffic.json (copy to profiles/rNN_pool_traffic.json)
+#   xstats[:B] / xlayers[:B] / xtraffic[:B]   extractor alone: kernel stats, per-convolution table, HBM bytes per call (PMC)
 #   bstats[:args] rocprofv3 --kernel-trace --stats of `python bench.py args`             ctraffic:"B H W Cin Cout k s p"  FETCH_SIZE of one convolution layer
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -47,6 +48,15 @@ for what in "$@"; do
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/xprof -o p -- python $ROOT/tools/extractor_bench.py ${arg:-512} 4 > $OUT/xprof.log 2>&1)
       python tools/summarize_rocprof.py $(find $OUT/xprof -name "*kernel_stats.csv" | head -1) "$TAG extractor, ${arg:-512} tiles per call" > $OUT/extractor_kernel_stats.md 2>&1
       head -24 $OUT/extractor_kernel_stats.md; tail -2 $OUT/xprof.log ;;
+    xlayers)        # per-convolution table from the xstats kernel trace (run xstats first)
+      python tools/extractor_layer_times.py $(find $OUT/xprof -name "*kernel_trace.csv" | head -1) ${arg:-512} > $OUT/extractor_layer_times.txt 2>&1; cat $OUT/extractor_layer_times.txt | head -30 ;;
+    xtraffic)       # HBM bytes of one extractor call: separate FETCH_SIZE / WRITE_SIZE passes -> extractor_traffic.json (copy to profiles/rNN_extractor_traffic.json)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/xtraffic/$c -o p -- python $ROOT/tools/extractor_bench.py ${arg:-512} 1 > $OUT/xtraffic_$c.log 2>&1)
+        find $OUT/xtraffic/$c -name "*.db" -delete
+      done
+      python tools/extractor_traffic_json.py $OUT/xtraffic ${arg:-512} 3 > $OUT/extractor_traffic.json 2> $OUT/extractor_traffic.err; head -12 $OUT/extractor_traffic.json; tail -3 $OUT/extractor_traffic.err
+      find $OUT/xtraffic -name "*counter_collection.csv" -size +20M -delete ;;
     ctraffic)       # HBM fetch bytes of one convolution layer: ctraffic:"B H W Cin Cout k s p"
       (cd /tmp && timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/ctraffic -o p -- python $ROOT/tools/conv_traffic.py $arg 3 > $OUT/ctraffic.log 2>&1)
       find $OUT/ctraffic -name "*.db" -delete
