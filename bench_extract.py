@@ -69,6 +69,24 @@ def cpu_extractor_baseline(n_tiles: int = 8, budget_s: float = 25.0):
                       + ", ".join(f"{k}: {v * 1e3:.0f} ms" for k, v in probe.items()) + "}"}
 
 
+TRAFFIC_FILE = "r04_extractor_traffic.json"      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one extractor call (tools/gpu_run.sh xtraffic)
+
+
+def extractor_traffic(chunk, n, ext_ms):
+    """HBM bytes of ONE extractor call (chunk tiles) from this round's PMC file, or None when the file was measured at another chunk size."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", TRAFFIC_FILE)) as f:
+            t = json.load(f)
+    except OSError:
+        return None, "no PMC file for this round"
+    if t.get("tiles_per_call") != chunk:
+        return None, f"profiles/{TRAFFIC_FILE} was measured at {t.get('tiles_per_call')} tiles per call"
+    per_call = t["hbm_bytes_per_call"]["total_with_fetch_x2"]
+    tbs = per_call * (n / chunk) / (ext_ms * 1e-3) / 1e12
+    return per_call, (f"HBM bytes per extractor call of {chunk} tiles (profiles/{TRAFFIC_FILE}: FETCH_SIZE x2 + WRITE_SIZE, separate passes); algorithmic "
+                      f"{t['algorithmic_bytes_per_call']} B; at this run's extractor time that is {tbs:.2f} TB/s of 8 nominal (5.9 measured for a read/write mix)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,6 +156,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         tf = FLOP_PER_TILE * n / (ext_ms * 1e-3)
+        traffic, traffic_what = extractor_traffic(chunk, n, ext_ms)
         out = {"metric": "patches/sec end-to-end: 256x256 tiles -> ResNet50-trunc -> bag -> attention-MIL step", "value": round(n * world * args.steps / elapsed, 1),
                "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (storage + accumulation; GEMM operands as 2 x f16 pieces, 3 MFMA terms)", "data": "synthetic",
@@ -148,7 +167,8 @@ def main():
                           "parallelism": f"slide-sharded dp{world}"},
                "roofline": {"bound": "mfma", "kernel": "43 conv-as-GEMM launches per chunk: conv3x3_h2_halo_kernel<2|4> (stride-1 3x3, activation halo in LDS) + gemm_nt_h2_stream_kernel<2,2|2,4> (Cout <= 128, short-K residual GEMMs, strided 3x3, stem: A streamed through registers) + gemm_nt_h2_big_kernel (Cout >= 256); + strided gathers, pools",
                             "achieved": round(tf / 1e12, 2), "peak": round(MFMA_EQ_PEAK / 1e12, 1), "unit": "TFLOP/s fp32-equivalent",
-                            "frac": round(tf / MFMA_EQ_PEAK, 4), "traffic": None, "fp16_mfma_tflops_issued": round(tf * SPLIT_TERMS / 1e12, 1),
+                            "frac": round(tf / MFMA_EQ_PEAK, 4), "traffic": traffic, "traffic_what": traffic_what,
+                            "fp16_mfma_tflops_issued": round(tf * SPLIT_TERMS / 1e12, 1),
                             "algorithmic_flops": FLOP_PER_TILE * n, "extractor_ms_per_step": round(ext_ms, 3),
                             "extractor_share_of_step": round(ext_ms / ms, 4)},
                "last_loss": round(float(losses[-1][0].item()) * world, 5)}
