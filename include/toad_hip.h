@@ -67,6 +67,10 @@ size_t toad_relu_bits_bytes(int64_t M, int64_t N);
  * K-split remainder tiles of the persistent 256x256 kernel, the split weight planes and, when x_amax == NULL, the
  * measured abs-max array; with ws == NULL, or K % 32 != 0, the generic 128x128 kernel runs instead.
  * x_amax: abs-max array of X or NULL.  y_amax: receives the abs-max array of Y, or NULL.
+ *   x_amax == NULL (ABI 10): there is no separate pass over X. The persistent kernel measures X while it converts it (a work item's scale
+ *   comes from its first 32 columns with 3 bits of head-room; a running maximum decides at the item's end whether the room sufficed, items
+ *   where it did not are repeated with the exact scale). Results equal the x_amax route to <= 5e-6 of max |Y| (both are exact products
+ *   under different power-of-two operand scales); the measured array is left in `ws` for the call's own K-split fix-up.
  * relu_bits_out (act = RELU, toad_linear_h2_ok shapes): receives the one-bit image of Y (toad_relu_bits_bytes), or NULL. */
 size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K);
 int toad_linear_act_fwd_f32(const float *X, const float *W, const float *bias, float *Y,
@@ -280,7 +284,8 @@ int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float *const *wei
  *                    (wab = [Wa;Wb] stacked [2D,512], bab = [ba;bb]); grads = beta*grads + d loss/d param.
  *   D in {256, 384}; X [N,1024] fp32, N >= 1 (an empty bag has no kernels to run: handle it in the host).
  *   drop_p, seed   : train-mode Dropout(drop_p) masks (0 = off), four streams derived from `seed`.
- *   x_amax         : abs-max array of X (toad_absmax_rows256_f32) or NULL = measured inside the call.
+ *   x_amax         : abs-max array of X (toad_absmax_rows256_f32) or NULL = measured inside the call - by the first GEMM itself while it
+ *                    converts the bag (no extra pass over X, see toad_linear_act_fwd_f32); arena slot 13 then receives the measured array.
  *
  * Memory. `arena` (toad_mil_arena_bytes) receives everything the backward needs and everything the caller reads:
  * toad_mil_arena_layout() returns the byte offset of each tensor in it, in this order (TOAD_MIL_ARENA_SLOTS entries):
