@@ -139,7 +139,7 @@ int launch_pool_fwd_batch(const float *Pa, const float *Pb, int64_t ldp, const f
 int launch_pool_bwd_batch(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *A_raw, const float *stats,
                           int s_stride, const float *M, const float *dM, int m_stride, float *dPa, float *dPb, int64_t ldd, float *dH, float *dWc,
                           float *dbc, float beta, void *ws, const int64_t *seg_dev, int B, int64_t max_n, int L, int D, int T, float drop_p,
-                          uint64_t seed_a, uint64_t seed_b, hipStream_t st);
+                          uint64_t seed_a, uint64_t seed_b, hipStream_t st, float *dp_amax = nullptr, float *row_bound = nullptr, int64_t n_rows = 0);
 // batched heads + weighted CE + heads backward of the ragged multi-slide step (heads.hip): one workgroup per slide, then the head-weight gradients
 struct HeadsBatch {          // per-slide records, all with the same byte stride `rec` (slide b of array p: (char *)p + b * rec)
     const float *M; float *Mcat, *logits, *yprob; int64_t *yhat; float *slog, *sprob; int64_t *shat; float *dM, *dl, *ds; size_t rec;

@@ -392,6 +392,7 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
         Pa += r0 * ldp; Pb += r0 * ldp; H += r0 * L_; A_raw += r0 * T_; dPa += r0 * ldd; dPb += r0 * ldd;
         if (dH) dH += r0 * L_;
         if (dA_ext) dA_ext += r0 * T_;
+        if (dp_amax) dp_amax += r0;                  // batched: ONE bound per row of the concatenation (slides do not line up with the 256-row blocks)
         stats += (int64_t)blockIdx.y * s_stride; Mp += (int64_t)blockIdx.y * m_stride; dM += (int64_t)blockIdx.y * m_stride;
         // slide y draws its tanh- / sigmoid-branch masks with seeds + 2 y G: the base seeds are seed + 3 G and seed + 4 G (step.hip drop_seeds), so the
         // tanh seeds stay on odd and the sigmoid seeds on even multiples of G and no slide's mask repeats another slide's other branch
@@ -542,11 +543,15 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
             for (int t = 0; t < T; ++t) bound = fmaf(__builtin_fabsf(ds[t]), wcm[t], bound);
             if (dropping) bound *= drop_a.scale * drop_b.scale;
             bound = valid ? bound : 0.f;
-            if (RPW == 2) bound = __builtin_fmaxf(bound, __shfl_xor(bound, 32));
-            else bound = h2_wave_max(bound);
-            // one plain store per wave step into a fine-grained table; bwd_partial_reduce_kernel folds 128 entries into each
-            // 256-row slot. (Device-scope atomics bypass the per-XCD L2s: 50,000 of them cost this kernel 30-40 us at N = 100k.)
-            if (lane == 0) dp_amax[tile * NW + wave] = bound;
+            if (seg) {                                   // batched: per-row table, folded 256 rows per slot by bwd_partial_reduce_kernel
+                if (c == 0 && valid) dp_amax[row] = bound;
+            } else {
+                if (RPW == 2) bound = __builtin_fmaxf(bound, __shfl_xor(bound, 32));
+                else bound = h2_wave_max(bound);
+                // one plain store per wave step into a fine-grained table; bwd_partial_reduce_kernel folds 128 entries into each
+                // 256-row slot. (Device-scope atomics bypass the per-XCD L2s: 50,000 of them cost this kernel 30-40 us at N = 100k.)
+                if (lane == 0) dp_amax[tile * NW + wave] = bound;
+            }
         }
     }
 
@@ -585,12 +590,13 @@ __global__ __launch_bounds__(POOL_THREADS) void gated_pool_bwd_kernel(
 __global__ __launch_bounds__(256) void bwd_partial_reduce_kernel(const float *__restrict__ partials, int G, int64_t rec,
                                                                   int n_w, int n_b, float *dWc, float *dbc,
                                                                   float beta, int nred, const float *__restrict__ fine,
-                                                                  int n_fine, float *__restrict__ dp_amax) {
+                                                                  int n_fine, float *__restrict__ dp_amax, int per_row) {
     __shared__ float red[64][4];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= nred) {
         // extra workgroups: abs-max slot of 256-row block rb = max over its 32 eight-row steps x NW waves of the fine table
-        constexpr int PER = (H2_ROWBLK / ROWS_PER_BLOCK_STEP) * NW;
+        // (per_row: the batched launch's table holds one bound per row)
+        const int PER = per_row ? H2_ROWBLK : (H2_ROWBLK / ROWS_PER_BLOCK_STEP) * NW;
         const int rb = blockIdx.x - nred;
         float v = 0.f;
         for (int e = tid; e < PER; e += 256) { const int i = rb * PER + e; if (i < n_fine) v = __builtin_fmaxf(v, fine[i]); }
@@ -752,16 +758,19 @@ int toad::launch_pool_fwd_batch(const float *Pa, const float *Pb, int64_t ldp, c
 int toad::launch_pool_bwd_batch(const float *Pa, const float *Pb, int64_t ldp, const float *H, const float *Wc, const float *A_raw, const float *stats,
                                 int s_stride, const float *M, const float *dM, int m_stride, float *dPa, float *dPb, int64_t ldd, float *dH, float *dWc,
                                 float *dbc, float beta, void *ws, const int64_t *seg_dev, int B, int64_t max_n, int L, int D, int T, float drop_p,
-                                uint64_t seed_a, uint64_t seed_b, hipStream_t st) {
+                                uint64_t seed_a, uint64_t seed_b, hipStream_t st, float *dp_amax, float *row_bound, int64_t n_rows) {
     const char *what = "toad_gated_pool_bwd_f32 (batched)";
     if (!shape_ok(L, D, T) || B < 1 || B > 4096) { set_error("%s: unsupported shape", what); return TOAD_ESHAPE; }
     const DropArgs da = make_drop(drop_p, seed_a), db = make_drop(drop_p, seed_b);
     const int gx = batch_gx(max_n, B);
-    launch_bwd(L, D, T, gx, st, Pa, Pb, ldp, H, Wc, A_raw, stats, M, dM, nullptr, dPa, dPb, ldd, dH, (float *)ws, nullptr, 0, da, db, seg_dev, B, m_stride, s_stride);
+    // dp_amax (optional) + row_bound (n_rows floats of scratch): the abs-max ARRAY of dP over the concatenation, from a per-row bound table
+    launch_bwd(L, D, T, gx, st, Pa, Pb, ldp, H, Wc, A_raw, stats, M, dM, nullptr, dPa, dPb, ldd, dH, (float *)ws, dp_amax ? row_bound : nullptr, 0, da, db, seg_dev, B,
+               m_stride, s_stride);
     if (int rc = check_launch(what)) return rc;
     const int n = T * D + T, nred = (n + 3) / 4;
-    hipLaunchKernelGGL(bwd_partial_reduce_kernel, dim3(nred), dim3(256), 0, st, (const float *)ws, gx * B, bwd_partial_floats(D, T), T * D, T, dWc, dbc, beta, nred,
-                       (const float *)nullptr, 0, (float *)nullptr);
+    const int nblk = dp_amax ? (int)((n_rows + H2_ROWBLK - 1) / H2_ROWBLK) : 0;
+    hipLaunchKernelGGL(bwd_partial_reduce_kernel, dim3(nred + nblk), dim3(256), 0, st, (const float *)ws, gx * B, bwd_partial_floats(D, T), T * D, T, dWc, dbc, beta, nred,
+                       (const float *)row_bound, (int)n_rows, dp_amax, 1);
     return check_launch(what);
 }
 
@@ -796,7 +805,7 @@ int toad::launch_pool_bwd(const float *Pa, const float *Pb, int64_t ldp, const f
     const int n = T * D + T, nred = (n + 3) / 4;
     const int nblk = dp_amax ? (int)((N + H2_ROWBLK - 1) / H2_ROWBLK) : 0;
     hipLaunchKernelGGL(bwd_partial_reduce_kernel, dim3(nred + nblk), dim3(256), 0, st, (const float *)ws, grid,
-                       bwd_partial_floats(D, T), T * D, T, dWc, dbc, beta, nred, (const float *)fine, (int)bwd_fine_floats(N), dp_amax);
+                       bwd_partial_floats(D, T), T * D, T, dWc, dbc, beta, nred, (const float *)fine, (int)bwd_fine_floats(N), dp_amax, 0);
     return check_launch(what);
 }
 

@@ -73,7 +73,7 @@ static void cfg() {
 #define TOAD_H2_ATTR(P, A_, M_) TOAD_ATTR((gemm_nt_h2_big_kernel<P, A_, M_, 0>), H2_SMEM)
         TOAD_H2_ATTR(false, false, 0); TOAD_H2_ATTR(false, false, 1); TOAD_H2_ATTR(false, false, 2);
         TOAD_H2_ATTR(true, false, 0); TOAD_H2_ATTR(true, false, 1); TOAD_H2_ATTR(true, false, 2);
-        TOAD_H2_ATTR(false, true, 0); TOAD_H2_ATTR(false, true, 1);
+        TOAD_H2_ATTR(false, true, 0); TOAD_H2_ATTR(false, true, 1); TOAD_H2_ATTR(false, true, 2);
 #undef TOAD_H2_ATTR
         TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 1>), H2_SMEM);
         TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 2>), H2_SMEM_PT);
@@ -286,7 +286,7 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
     const int msk = mask_bits ? 2 : (mask_src ? 1 : 0);
     if (mask_bits && !mask_src) { set_error("%s: the one-bit ReLU image needs the fp32 relu_src as well (remainder tiles)", what); return TOAD_EINVAL; }
     if (pool.T > 0) { if (msk == 2) TOAD_LAUNCH_H2(true, false, 2); else if (msk == 1) TOAD_LAUNCH_H2(true, false, 1); else TOAD_LAUNCH_H2(true, false, 0); }
-    else if (addend) { if (msk) { msrc = mask_src; TOAD_LAUNCH_H2(false, true, 1); } else TOAD_LAUNCH_H2(false, true, 0); }
+    else if (addend) { if (msk == 2) TOAD_LAUNCH_H2(false, true, 2); else if (msk == 1) TOAD_LAUNCH_H2(false, true, 1); else TOAD_LAUNCH_H2(false, true, 0); }
     else { if (msk == 2) TOAD_LAUNCH_H2(false, false, 2); else if (msk == 1) TOAD_LAUNCH_H2(false, false, 1); else TOAD_LAUNCH_H2(false, false, 0); }
 #undef TOAD_LAUNCH_H2
     int rc = check_launch(what);

@@ -548,7 +548,7 @@ extern "C" int toad_mil_multi_step_f32(const float *const *params, float *const 
     if (!self_measure) TOAD_TRY(launch_absmax(Xcat, kL0, N, kL0, f.amax_x, false, st, what));
     ev(2); TOAD_TRY(launch_nt_h2(Xcat, kL0, self_measure ? nullptr : f.amax_x, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool,
                                  w.slabs, f.amax_h1, f.bits_h1, st, what, TOAD_X_F32, 1, 1, self_measure ? f.amax_x : nullptr, self_measure ? w.slab_ke : nullptr)); ev(3);
-    ev(4); TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h, nullptr, st, what)); ev(5);
+    ev(4); TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h, f.bits_h, st, what)); ev(5);
     ev(6); TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nullptr, nopool, w.slabs, nullptr, nullptr, st, what)); ev(7);
     // ---- all slides at once (blockIdx.y = slide): fused pool forward on each row range + merge; heads + weighted CE + heads backward with
     // one workgroup per slide, then the head-weight gradients summed over the batch; pooling backward (dP rows, the pooling gradient
@@ -571,14 +571,15 @@ extern "C" int toad_mil_multi_step_f32(const float *const *params, float *const 
         return TOAD_EINVAL;
     }
     TOAD_TRY(launch_pool_bwd_batch(f.P, f.P + D, D2, f.H, p.wc, f.A_raw, ms.stats, rec_f, ms.M, ms.dM, rec_f, w.dP, w.dP + D, D2, w.dZ2, grads[6], grads[7], beta,
-                                   ms.pool_ws, ms.seg, B, max_n, kL, D, kT, drop_p, ds.sa, ds.sb, st));
-    // the slides' row ranges do not line up with the 256-row blocks of the concatenation: dP's abs-max array is measured in one pass
-    TOAD_TRY(launch_absmax(w.dP, D2, N, D2, w.amax_dP, false, st, what));
+                                   ms.pool_ws, ms.seg, B, max_n, kL, D, kT, drop_p, ds.sa, ds.sb, st, w.amax_dP, w.dZ1, N));
+    // (the slides' row ranges do not line up with the 256-row blocks of the concatenation: the pool backward leaves one upper bound of |dP| per ROW -
+    // in dZ1's buffer, which nobody has written yet - and its reduce kernel folds 256 of them into each slot of dP's abs-max array. Round 3 measured
+    // the array in a pass of its own over dP: 307 MB read per 100k rows.)
     // ---- backward GEMMs over all rows
     WgradDeferred dw[3];
     ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what, TOAD_X_F32, &dw[0])); ev(9);
     // dZ2 = (dP Wab + dH_pool) * (H > 0), in place over the materialised dH_pool
-    ev(10); TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, w.dZ2, f.H, nullptr, nopool, w.slabs,
+    ev(10); TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, w.dZ2, f.H, f.bits_h, nopool, w.slabs,
                                   w.amax_dZ2, nullptr, st, what)); ev(11);
     ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws2, st, what, TOAD_X_F32, &dw[1])); ev(13);
     ev(14); TOAD_TRY(launch_nt_h2(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, f.bits_h1, nopool, w.slabs,
