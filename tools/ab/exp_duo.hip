@@ -53,7 +53,7 @@ extern "C" int toad_exp_ext_f32(int which, const float *X, const float *x_gmax, 
     if (int rc = launch_split_h2(&op, 1, nullptr, 0, st, what)) return rc;
     EpiScalars es{act == TOAD_ACT_RELU, 1.f, make_drop(0.f, 0)};
     const H2Pool nopool{nullptr, nullptr, nullptr, 0};
-    if (which >= 2) es.stagger = which;              // which >= 2: the shipped kernel with a staggered start, which = the period in 10 ns ticks
+    if (which >= 2 || which <= -2) es.stagger = which < 0 ? -which : which;      // |which| >= 2: a staggered start over that many 10 ns ticks; negative: on the duo kernel
     if (which == 0 || which >= 2)
         return launch_nt_h2(X, K, x_gmax, planes, binv, Y, N, M, N, K, bias, es, residual, nullptr, nullptr, nopool, slabs, y_gmax, nullptr, st, what, TOAD_X_F32, 0, 0);
     return launch_nt_h2_duo(X, K, x_gmax, planes, binv, Y, N, M, N, K, bias, es, residual, nullptr, nullptr, nopool, y_gmax, nullptr, st, what, nullptr, 0, 0);
