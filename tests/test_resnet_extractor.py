@@ -147,13 +147,19 @@ def test_stem_with_the_maxpool_in_its_epilogue_is_bitwise_the_two_kernel_path(cu
                                            (2048, 2304, 256, False, 1), (300, 160, 64, False, 1), (512, 256, 1024, True, 0),
                                            # streamed kernels with more tiles than workgroups (cross-tile prefetch, one weight chunk per tile), ragged M
                                            (140001, 64, 128, True, 1), (200003, 64, 64, False, 1), (133000, 192, 100, False, 0),
-                                           (3000, 32, 256, True, 1)])      # K = 32 with a residual: narrow tiles, two column tiles, padded planes
+                                           (3000, 32, 256, True, 1),       # K = 32 with a residual: narrow tiles, two column tiles, padded planes
+                                           # the 256x256 kernel with staggered workgroup starts (K <= 512, M >= 32k: gemm_f32.hip ext_linear) and the
+                                           # two-then-four-deep residual prefetch, ragged last row tile, K-split remainder tiles
+                                           (40001, 128, 512, True, 1), (33000, 256, 1024, True, 0), (70000, 512, 256, False, 1)])
 def test_linear_act_res_matches_fp64(cuda, m, k, n, res, act):
     from toad_amd import ops
     g = torch.Generator().manual_seed(m + k + n)
     x = torch.randn(m, k, generator=g); w = torch.randn(n, k, generator=g) / k ** 0.5; b = torch.randn(n, generator=g)
     r = torch.randn(m, n, generator=g) if res else None
-    y = ops.linear_act_res_fwd(x.to(cuda), w.to(cuda), b.to(cuda), None if r is None else r.to(cuda), act).cpu()
+    args = (x.to(cuda), w.to(cuda), b.to(cuda), None if r is None else r.to(cuda), act)
+    y_dev = ops.linear_act_res_fwd(*args)
+    assert torch.equal(y_dev, ops.linear_act_res_fwd(*args))                    # run-to-run bitwise (staggered starts change timing, never values)
+    y = y_dev.cpu()
     ref = x.double() @ w.double().t() + b.double() + (0 if r is None else r.double())
     if act:
         ref = ref.clamp_min(0)
