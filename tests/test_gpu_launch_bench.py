@@ -37,3 +37,27 @@ def test_config4_through_the_torchrun_path_with_rccl(cuda):
     for key in ("roofline", "roofline_mfma"):
         assert 0 < out[key]["frac"] < 1, key
     assert out["roofline_mfma"]["rows"] == 2 * 64 * 50000
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("extra,scaling,slides", [([], "weak", 2), (["--config", "4"], "strong", 64)])
+def test_world_two_plumbing_on_one_gpu_over_gloo(cuda, extra, scaling, slides):
+    """Everything of `bench.py --gpus N` that does not need a second device, at N = 2: self-launch of two ranks (toad_amd/launch.py), rendezvous on
+    127.0.0.1, slide sharding, the gradient all-reduce inside every step, barrier + max-over-ranks timing, the per-rank attribution keys and ONE
+    JSON line from rank 0. RCCL refuses two ranks on one GPU, so the collective runs over gloo here (`--single-device --backend gloo`: a plumbing
+    switch, never a measurement); the RCCL call itself is covered at world 1 above."""
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--single-device", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-dropin", "--sustain-seconds", "0"] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["steps"] == 2 and out["config"]["slides_per_step"] == slides
+    assert out["allreduce"]["world"] == 2 and out["allreduce"]["us"] > 0
+    pr = out["per_rank"]
+    assert len(pr["step_ms"]) == 2 and len(pr["allreduce_us"]) == 2 and len(pr["patches_per_step"]) == 2
+    assert pr["patches_per_step"][0] == pr["patches_per_step"][1]              # both configurations shard evenly over two ranks
+    assert max(pr["step_ms"]) <= out["ms_per_step"] * 1.05                      # the line's time is the max over ranks (barrier included)
+    assert out["value"] > 0 and abs(out["value"] - slides * 1e3 / out["ms_per_step"]) <= 1e-2 * out["value"]
