@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOAD_ABI_VERSION 11
+#define TOAD_ABI_VERSION 12
 
 enum { TOAD_OK = 0, TOAD_EINVAL = -1, TOAD_ESHAPE = -2, TOAD_EWORKSPACE = -3, TOAD_EALIGN = -4 };
 enum { TOAD_ACT_NONE = 0, TOAD_ACT_RELU = 1 };
@@ -256,6 +256,11 @@ int toad_stem_conv_s2d_f32(const float *Xs, const float *Wf, const float *bias, 
  * toad_stem_conv_s2d_f32(.., TOAD_ACT_RELU). Shapes: Wo == 128 (tiles 256 wide) and Ho even; TOAD_ESHAPE otherwise. */
 int toad_stem_conv_pool_s2d_f32(const float *Xs, const float *Wf, const float *bias, float *Yp, int B, int Ho, int Wo,
                                 void *ws, size_t ws_bytes, void *stream);
+/* The same result straight from the NCHW tiles X [B,3,H,W] (no space-to-depth image): the window of a tile of two conv rows is loaded into LDS in
+ * whole image rows, converted once, and every MFMA operand comes from there. Wf as for toad_stem_conv_s2d_f32. Shapes: W == 256, H % 4 == 0;
+ * TOAD_ESHAPE otherwise. Values agree with the two routes above to fp32 round-off (one power-of-two operand scale per tile instead of per call). */
+int toad_stem_pool_nchw_f32(const float *X, const float *Wf, const float *bias, float *Yp, int B, int H, int W,
+                            void *ws, size_t ws_bytes, void *stream);
 
 /* nn.MaxPool2d(kernel 3, stride 2, padding 1) (:66) on NHWC; C % 4 == 0. Y is [B, Ho, Wo, C]. */
 int toad_maxpool3x3s2_nhwc_f32(const float *X, float *Y, int B, int H, int W, int C, void *stream);

@@ -143,6 +143,33 @@ def test_stem_with_the_maxpool_in_its_epilogue_is_bitwise_the_two_kernel_path(cu
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,h", [(1, 256), (3, 256), (5, 64), (37, 128), (7, 4), (2, 12), (300, 256)])
+def test_stem_and_pool_straight_from_nchw_tiles(cuda, b, h):
+    """stem_halo.inc: conv 7x7/2 + ReLU + max-pool 3x3/2 (models/resnet_custom.py:96-99) from the NCHW tiles, window in LDS, per-tile operand scale.
+    Against the fp64 reference and against the two-kernel route (which differs only in the power of two the operand is scaled by)."""
+    from toad_amd import ops
+    g = torch.Generator().manual_seed(b * 1000 + h + 7)
+    x = torch.randn(b, 3, h, 256, generator=g) * torch.rand(b, 1, 1, 1, generator=g).mul(3).exp()       # images of different brightness
+    x[0, :, : h // 2] = 0.0                                                                              # a tile whose whole window is zero
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    bias = torch.randn(64, generator=g)
+    w8 = torch.zeros(64, 3, 8, 8); w8[:, :, 1:, 1:] = wt
+    wf = w8.view(64, 3, 4, 2, 4, 2).permute(0, 2, 4, 3, 5, 1).reshape(64, 192).contiguous().to(cuda)
+    xd = x.to(cuda)
+    one = ops.stem_pool_nchw(xd, wf, bias.to(cuda))
+    assert torch.equal(one, ops.stem_pool_nchw(xd, wf, bias.to(cuda)))
+    two = ops.maxpool3x3s2_nhwc(ops.stem_conv(xd, wf, bias.to(cuda), 1))
+    assert one.shape == two.shape == (b, h // 4, 64, 64)
+    scale = float(two.abs().max())
+    assert (one - two).abs().max().item() <= 2e-6 * scale, (one - two).abs().max().item() / scale
+    if b <= 40:
+        ref = F.max_pool2d(F.conv2d(x.double(), wt.double(), bias.double(), stride=2, padding=3).clamp_min(0), 3, 2, 1).permute(0, 2, 3, 1)
+        assert (one.cpu().double() - ref).abs().max().item() <= 2e-6 * scale
+    with pytest.raises(RuntimeError, match="W = 256"):
+        ops.stem_pool_nchw(xd[:, :, :, :128].contiguous(), wf, bias.to(cuda))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("m,k,n,res,act", [(4096, 64, 64, False, 1), (1000, 576, 64, False, 1), (777, 128, 512, True, 1),
                                            (2048, 2304, 256, False, 1), (300, 160, 64, False, 1), (512, 256, 1024, True, 0),
                                            # streamed kernels with more tiles than workgroups (cross-tile prefetch, one weight chunk per tile), ragged M

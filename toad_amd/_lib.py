@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TOAD_HIP_LIB", os.path.join(_HERE, "libtoad_hip.so"))   # override: kernel A/B builds only
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 P, I64, I, F, SZ, U64 = c_void_p, c_int64, c_int, c_float, c_size_t, c_uint64
 
@@ -47,6 +47,7 @@ SIGNATURES = {
     "toad_stem_s2d_nchw_f32": (I, [P, P, I, I, I, P]),
     "toad_stem_conv_s2d_f32": (I, [P, P, P, P, I, I, I, I, P, SZ, P]),
     "toad_stem_conv_pool_s2d_f32": (I, [P, P, P, P, I, I, I, P, SZ, P]),
+    "toad_stem_pool_nchw_f32": (I, [P, P, P, P, I, I, I, P, SZ, P]),
     "toad_maxpool3x3s2_nhwc_f32": (I, [P, P, I, I, I, I, P]),
     "toad_avgpool_nhwc_f32": (I, [P, P, I, I, I, P]),
     "toad_resnet50_trunc_ws_bytes": (SZ, [I, I, I]),

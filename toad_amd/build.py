@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtoad_hip.so")
 SOURCES = ["capi.hip", "gemm_f32.hip", "gated_pool.hip", "heads.hip", "step.hip", "conv.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(REPO, "include", "toad_hip.h")] + \
-    [os.path.join(CSRC, f) for f in ("gemm_nt_f32.inc", "gemm_tn.inc", "gemm_h2.inc", "gemm_h2_epilogue.inc", "gemm_pt.inc", "gemm_narrow.inc", "gemm_stream.inc")]
+    [os.path.join(CSRC, f) for f in ("gemm_nt_f32.inc", "gemm_tn.inc", "gemm_h2.inc", "gemm_h2_epilogue.inc", "gemm_pt.inc", "gemm_narrow.inc", "gemm_stream.inc", "stem_halo.inc")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
          "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 

@@ -130,6 +130,9 @@ int ext_conv_nhwc(const float *X, const float *x_gmax, const float *Wf, const fl
                   const char *what);
 int ext_stem_conv(const float *Xs, const float *x_gmax, const float *Wf, const float *bias, float *Y, float *y_gmax, int B, int Ho, int Wo, int act,
                   void *ws, size_t ws_bytes, hipStream_t st, const char *what, bool pooled = false);
+bool stem_nchw_pool_ok(int H, int W);                 // the stem + pool may run straight from the NCHW tiles (stem_halo.inc)
+int ext_stem_nchw_pool(const float *X, const float *Wf, const float *bias, float *Yp, float *y_gmax, int B, int H, int W, void *ws, size_t ws_bytes,
+                       hipStream_t st, const char *what);
 bool stem_pool_ok(int Ho, int Wo, int act);           // the stem may take the 3x3/2 max-pool into its epilogue (gemm_stream.inc)
 // batched pooling launches of the ragged multi-slide step (gated_pool.hip): blockIdx.y = slide, row ranges from the DEVICE array seg_dev [B+1]
 size_t pool_batch_ws_bytes(int B, int L, int D, int T);

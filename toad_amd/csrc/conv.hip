@@ -295,16 +295,22 @@ extern "C" int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float 
 #define TOAD_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
     // stem: 7x7/2 conv + BN + ReLU (resnet_custom.py:96-98), 3x3/2 max-pool (:99)
     float *g_in = slot();
+    float *gx = slot();
+    if (stem_nchw_pool_ok(H, W) && aligned16(tiles_nchw)) {
+        // 256-wide tiles: stem + ReLU + max-pool as ONE kernel reading the NCHW tiles themselves (stem_halo.inc); per-tile operand scales, so not even
+        // max |tiles| is measured
+        TOAD_TRY(ext_stem_nchw_pool(tiles_nchw, weights[0], biases[0], act[1], gx, B, H, W, gws, gcap, st, what));
+    } else {
     // 12-channel space-to-depth image (53 MB per 64 tiles); the gather also emits max |tiles| - the only measured tensor - into its slot
     if (!aligned16(cols)) { set_error("%s: internal: cols not aligned", what); return TOAD_EALIGN; }
     hipLaunchKernelGGL(stem_s2d_kernel, dim3(grid_for((uint64_t)B * (p.Hs + 3) * (p.Ws + 3))), dim3(256), 0, st, tiles_nchw, cols, B, H, W, p.Hs + 3, p.Ws + 3, g_in);
     TOAD_TRY(check_launch(what));
-    float *gx = slot();
     if (stem_pool_ok(p.Hs, p.Ws, TOAD_ACT_RELU)) {      // tiles 256 wide: the max-pool rides in the stem's epilogue, the stem's own output is never stored
         TOAD_TRY(ext_stem_conv(cols, g_in, weights[0], biases[0], act[1], gx, B, p.Hs, p.Ws, TOAD_ACT_RELU, gws, gcap, st, what, true));
     } else {
         TOAD_TRY(ext_stem_conv(cols, g_in, weights[0], biases[0], act[0], gx, B, p.Hs, p.Ws, TOAD_ACT_RELU, gws, gcap, st, what));
         TOAD_TRY(toad_maxpool3x3s2_nhwc_f32(act[0], act[1], B, p.Hs, p.Ws, 64, st));      // max-pooling keeps the maximum: same slot
+    }
     }
     float *x = act[1];                          // block input (abs-max scalar: gx)
     auto other = [&](float *a0, float *a1, float *a2) {          // a buffer different from the (up to) three in use

@@ -55,6 +55,7 @@ __device__ __forceinline__ bool map_tile(int tiles_m, int tiles_n, int &tm, int 
 #include "gemm_pt.inc"
 #include "gemm_narrow.inc"
 #include "gemm_stream.inc"
+#include "stem_halo.inc"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -89,6 +90,7 @@ static void cfg() {
         TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 4, GATHER_CONV>), (StreamCfg<2, 4>::SMEM));
         TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 2, GATHER_STEM>), (StreamCfg<2, 2>::SMEM));
         TOAD_ATTR((gemm_nt_h2_stream_kernel<2, 2, GATHER_STEM_POOL>), (StreamCfg<2, 2>::SMEM + STEM_POOL_LDS));
+        TOAD_ATTR(stem_halo_pool_kernel, SH_SMEM);
         TOAD_ATTR(conv3x3_h2_halo_kernel<2>, 160 * 1024);
         TOAD_ATTR(conv3x3_h2_halo_kernel<4>, 160 * 1024);
 #undef TOAD_ATTR
@@ -579,6 +581,30 @@ extern "C" int toad_stem_conv_s2d_f32(const float *Xs, const float *Wf, const fl
 extern "C" int toad_stem_conv_pool_s2d_f32(const float *Xs, const float *Wf, const float *bias, float *Yp, int B, int Ho, int Wo, void *ws, size_t ws_bytes,
                                            void *stream) {
     return ext_stem_conv(Xs, nullptr, Wf, bias, Yp, nullptr, B, Ho, Wo, TOAD_ACT_RELU, ws, ws_bytes, (hipStream_t)stream, "toad_stem_conv_pool_s2d_f32", true);
+}
+
+// The stem + ReLU + 3x3/2 max-pool straight from NCHW tiles (stem_halo.inc): no space-to-depth image, no fragment loads from global memory.
+bool toad::stem_nchw_pool_ok(int H, int W) { return W == 256 && H >= 4 && H % 4 == 0; }
+int toad::ext_stem_nchw_pool(const float *X, const float *Wf, const float *bias, float *Yp, float *y_gmax, int B, int H, int W, void *ws, size_t ws_bytes,
+                             hipStream_t st, const char *what) {
+    if (!X || !Wf || !Yp || !ws) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
+    if (B <= 0 || !stem_nchw_pool_ok(H, W)) { set_error("%s: needs W = 256 and H %% 4 == 0 (other tiles: toad_stem_s2d_nchw_f32 + toad_stem_conv_s2d_f32 + toad_maxpool3x3s2_nhwc_f32)", what); return TOAD_ESHAPE; }
+    const int64_t M = (int64_t)B * (H / 2) * 128;
+    if (M >= (1ll << 31)) { set_error("%s: batch too large for 32-bit offsets (split it)", what); return TOAD_ESHAPE; }
+    if (!aligned16(X) || !aligned16(Wf) || !aligned16(Yp) || (bias && !aligned16(bias))) { set_error("%s: pointers must be 16-byte aligned", what); return TOAD_EALIGN; }
+    if (int rc = check_ws(ws, ws_bytes, M, 64, 192, what)) return rc;
+    (void)cfg();
+    char *w = reinterpret_cast<char *>(ws) + (size_t)PB_GRID * PB * PB * sizeof(float);
+    unsigned short *planes = reinterpret_cast<unsigned short *>(w);
+    float *binv = reinterpret_cast<float *>(w + (size_t)64 * 6 * BK * 4);
+    hipLaunchKernelGGL(split_planes_narrow_h2_kernel<2>, dim3(16), dim3(256), 0, st, Wf, (int64_t)192, planes, binv, 64, 192, 1, 1, 12, 6);
+    if (int rc = check_launch(what)) return rc;
+    const int tiles = B * (H / 4);
+    hipLaunchKernelGGL(stem_halo_pool_kernel, dim3(std::min(tiles, PB_GRID)), dim3(256), SH_SMEM, st, X, planes, binv, bias, Yp, B, H, y_gmax, tiles);
+    return check_launch(what);
+}
+extern "C" int toad_stem_pool_nchw_f32(const float *X, const float *Wf, const float *bias, float *Yp, int B, int H, int W, void *ws, size_t ws_bytes, void *stream) {
+    return ext_stem_nchw_pool(X, Wf, bias, Yp, nullptr, B, H, W, ws, ws_bytes, (hipStream_t)stream, "toad_stem_pool_nchw_f32");
 }
 
 extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const float *addend, const float *relu_src,

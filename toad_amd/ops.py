@@ -776,6 +776,20 @@ def stem_conv_pool(x: torch.Tensor, wf: torch.Tensor, b) -> torch.Tensor:
     return y
 
 
+def stem_pool_nchw(x: torch.Tensor, wf: torch.Tensor, b) -> torch.Tensor:
+    """Stem + ReLU + 3x3/2 max-pool straight from NCHW tiles (W == 256, H % 4 == 0): x [B,3,H,W] -> [B,H/4,64,64] NHWC; the values of
+    maxpool3x3s2_nhwc(stem_conv(x, wf, b, ACT_RELU)) to fp32 round-off (per-tile operand scales)."""
+    _chk(x, "x"); _chk(wf, "wf"); _chk(b, "b", allow_none=True)
+    bb, c, h, w = x.shape
+    if c != 3 or tuple(wf.shape) != (64, 192):
+        raise ValueError("stem_pool_nchw: expected [B,3,H,W] tiles and a [64,192] space-to-depth weight")
+    y = torch.empty((bb, h // 4, w // 4, 64), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws = _ws(lib.toad_linear_ws_bytes(bb * (h // 2) * (w // 2), 64, 192), x.device)
+    _lib.check(lib.toad_stem_pool_nchw_f32(_p(x), _p(wf), _p(b), _p(y), bb, h, w, _p(ws), ws.numel(), _stream()), "toad_stem_pool_nchw_f32")
+    return y
+
+
 def maxpool3x3s2_nhwc(x: torch.Tensor) -> torch.Tensor:
     _chk(x, "x")
     b, h, w, c = x.shape
