@@ -165,7 +165,7 @@ def main():
                           "arithmetic": "fp32 storage/accumulation; conv-as-GEMM operands as two fp16 pieces (3 MFMA terms, one tensor-wide power-of-two "
                                         "scale per activation from producer-emitted abs-max scalars, per-row scales for the weights) = fp32-equivalent",
                           "parallelism": f"slide-sharded dp{world}"},
-               "roofline": {"bound": "mfma", "kernel": "43 conv-as-GEMM launches per chunk: conv3x3_h2_halo_kernel<2|4> (stride-1 3x3, activation halo in LDS) + gemm_nt_h2_stream_kernel<2,2|2,4> (Cout <= 128, short-K residual GEMMs, strided 3x3, stem: A streamed through registers) + gemm_nt_h2_big_kernel (Cout >= 256); + strided gathers, pools",
+               "roofline": {"bound": "mfma", "kernel": "43 conv-as-GEMM launches per chunk: stem_halo_pool_kernel (stem + max-pool from the NCHW tiles, window in LDS) + conv3x3_h2_halo_kernel<2|4> (stride-1 3x3, activation halo in LDS) + gemm_nt_h2_stream_kernel<2,2|2,4> (Cout <= 128, short-K residual GEMMs, strided 3x3: A streamed through registers) + gemm_nt_h2_big_kernel (Cout >= 256); + strided gathers, average pool",
                             "achieved": round(tf / 1e12, 2), "peak": round(MFMA_EQ_PEAK / 1e12, 1), "unit": "TFLOP/s fp32-equivalent",
                             "frac": round(tf / MFMA_EQ_PEAK, 4), "traffic": traffic, "traffic_what": traffic_what,
                             "fp16_mfma_tflops_issued": round(tf * SPLIT_TERMS / 1e12, 1),

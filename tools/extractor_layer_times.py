@@ -5,7 +5,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 g = [((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, r['Kernel_Name']) for r in rows
-     if 'gemm_nt_h2' in r['Kernel_Name'] or 'gemm_nt_split' in r['Kernel_Name'] or 'conv3x3_h2' in r['Kernel_Name']]
+     if 'gemm_nt_h2' in r['Kernel_Name'] or 'gemm_nt_split' in r['Kernel_Name'] or 'conv3x3_h2' in r['Kernel_Name'] or 'stem_halo_pool' in r['Kernel_Name']]
 last = g[-43:]
 order = [("stem", B * 128 * 128, 147, 64)]   # algorithmic K (the kernel runs the 192-column space-to-depth operand)
 inpl, hh = 64, 64
@@ -23,7 +23,7 @@ agg, tot, totf = {}, 0.0, 0.0
 for (name, M, K, N), (us, kn) in zip(order, last):
     fl = 2 * M * K * N
     tot += us; totf += fl
-    kind = ("halo" + kn.split("halo_kernel")[1].split("(")[0] if "halo" in kn else "stream" + kn.split("stream_kernel")[1].split("(")[0] if "stream" in kn else
+    kind = ("stem from NCHW + pool" if "stem_halo_pool" in kn else "halo" + kn.split("halo_kernel")[1].split("(")[0] if "halo" in kn else "stream" + kn.split("stream_kernel")[1].split("(")[0] if "stream" in kn else
             "narrow" + kn.split("narrow_kernel")[1].split("(")[0] if "narrow" in kn else "big" + ("+res" if "false, true" in kn else ""))
     a = agg.setdefault((M, K, N, kind), [0, 0.0, 0.0]); a[0] += 1; a[1] += us; a[2] += fl
 print(f"{'M':>8} {'K':>5} {'N':>5} {'kernel':<20} {'n':>2} {'us each':>8} {'TF-eq':>6} {'total us':>9} {'HBM floor us (each)':>10}")

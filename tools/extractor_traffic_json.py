@@ -25,7 +25,7 @@ write = sum(v["write_kb"] for v in per.values()) * 1024
 # algorithmic bytes of the call: every activation tensor written once and read once by each consumer (fp32 NHWC), input tiles read once
 def algorithmic(B):
     t = B * 3 * 256 * 256 * 4                                # input tiles (read by the space-to-depth gather)
-    t += 2 * B * 128 * 128 * 12 * 4                          # s2d image written + read (x ~1 through L2 for the 4x4 windows)
+    # (256-wide tiles: the stem reads the NCHW tiles themselves - no space-to-depth image)
     t += B * 64 * 64 * 64 * 4                                # pooled stem output written (the pool rides in the stem's epilogue: the stem's own output never exists)
     inpl, hh = 64, 64
     for pl, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2)):
