@@ -228,6 +228,11 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
                         int *slab_ke) {
     const int tiles_m = (int)((M + PB - 1) / PB), tiles_n = (int)((N + PB - 1) / PB);
     (void)cfg();
+    // Staggered workgroup starts (gemm_h2.inc) for launches of at least two tiles per workgroup: the 32 workgroups of an XCD start spread over
+    // ~2/5 of a tile period (1.95 us per k-step + ~8 us of epilogue), so their epilogue store bursts and LOAD phases no longer coincide.
+    // Same-box sweep on the 100k-patch step (profiles/r04u_stagger_mil_step.txt): 2.125 -> 2.083 ms; per GEMM the best spread is about a third
+    // of its period (K = 512: 10-15 us, K = 1024: 20-25 us). Round 3's four-phase version of this was neutral. Timing only: values never change.
+    if (es.stagger == 0 && (int64_t)tiles_m * tiles_n >= 2 * PB_GRID) es.stagger = (int)(((K / BK) * 195 + 800) * 2 / 5);
     // a_amax == NULL with a_amax_out (fp32 A, plain forward): the kernel measures A itself, stage by stage (AMODE 3, gemm_h2.inc), fills
     // a_amax_out (zeroed by the caller) and slab_ke; the fix-up then reads the completed array
     const bool run_mode = a_mode == TOAD_X_F32 && !a_amax && a_amax_out;
