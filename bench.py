@@ -614,7 +614,7 @@ def main():
             "config": {"workload": f"TOAD_fc_mtl_concat(big, n_classes=18) fwd + 0.75/0.25 CE + bwd + Adam on "
                                    f"{len(slides[0])} x {n}-patch x 1024-d N(0,1) fp32 bag(s) per GPU per step, bags resident in HBM"
                                    + (" in the ingest format (toad_bag_prepare_f32 BEFORE the timed region: both fp16 pieces of every fp32 element, plane-tiled, 4 B/element)"
-                                      if prepared else " as raw fp32 tensors; the abs-max pass over the bag and its split into the GEMM operand pieces run inside every timed step")
+                                      if prepared else " as raw fp32 tensors; measuring the bag (abs-max, inside the first GEMM) and splitting it into the GEMM operand pieces happen inside every timed step")
                                    + (f"; 64 slides per optimiser step dealt round robin over {world} rank(s)" if args.config == 4 else ""),
                        "arithmetic": "fp32 storage/accumulation; GEMM operands as two fp16 pieces (x*s = h+m, power-of-two scales), 3 MFMA terms = "
                                      "fp32-equivalent, verified vs fp64 (tools/split_emulation.py, tests/test_gpu_h2.py)",
