@@ -248,3 +248,61 @@ def check_activations_vs_golden(golden, name, h1_dev, h_dev, atol=1e-4):
 # VALUES (which a flip moves by round-off) and never of the masks, so they are compared with the reference's golden values always.
 MASK_FREE_KEYS = tuple(k for k in orc.PARAM_KEYS if not (k.startswith("attention_net.0.") or k.startswith("attention_net.2.")))
 LAYER2_KEYS = tuple(k for k in orc.PARAM_KEYS if k.startswith("attention_net.2."))
+
+
+def check_batch_against_oracle(name, params, slides, offs, dev, grads, masks=None):
+    """The checker behind tests/test_gpu_multi_step.py::test_config4_shape_batches_match_the_oracle (and its CPU self-test in
+    tests/test_oracle_golden.py). ``slides``: [(x, sex, label, site)] CPU tensors; ``offs``: row offsets of the concatenation; ``dev``: what the
+    device produced, as CPU tensors - h1, h [rows, 512], p [rows, 2D], a_raw [rows, 2] of the concatenation, logits [B, C], site_logits [B, 2],
+    loss [B, 3] (scaled by 1/B like the call's loss weights); ``grads``: {slot: gradient of the batch}; ``masks``: per slide the exported dropout
+    multipliers {"h1", "h", "a", "b"} or None. Reference semantics: utils/core_utils_mtl_concat.py:200-234 per slide, models/model_toad.py:90-116.
+      * per slide: logits / site logits / loss / A_raw against the oracle's fp32 forward, 1e-4 absolute;
+      * H1 / H against the exact fp64 forward, 1e-4 of their abs-max; where the device's ReLU mask differs from the exact one the exact
+        pre-activation must be round-off of zero;
+      * all 14 gradients against the sum over slides of the oracle's fp64 backward on the DEVICE's activations (identical masks): 2e-5 of each
+        gradient's own scale + 10 x (32 x for the three cancellation-dominated ones) the fp32 noise of the same backward.
+    Returns (sum of fp32 backward, sum of fp64 backward, [mask differences layer 1, layer 2])."""
+    B = len(slides)
+    p64 = {k: v.double() for k, v in params.items()}
+    tot64 = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in params.items()}
+    tot32 = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in params.items()}
+    flips = [0, 0]
+    for b, (x, sx, lb, st) in enumerate(slides):
+        r0, r1 = offs[b], offs[b + 1]
+        mk = None if masks is None else masks[b]
+        o_out, _ = orc.forward(params, x, sx, masks=mk)
+        o_loss = orc.loss_fn(o_out["logits"], lb, o_out["site_logits"], st)
+        assert (dev["logits"][b] - o_out["logits"][0]).abs().max().item() <= 1e-4, (name, b, "logits")
+        assert (dev["site_logits"][b] - o_out["site_logits"][0]).abs().max().item() <= 1e-4, (name, b, "site_logits")
+        assert abs(dev["loss"][b][0].item() * B - float(o_loss)) <= 1e-4, (name, b, "loss")
+        assert (dev["a_raw"][r0:r1] - o_out["A"].t()).abs().max().item() <= 1e-4, (name, b, "A_raw")
+        z1 = torch.addmm(p64["attention_net.0.bias"], x.double(), p64["attention_net.0.weight"].t())
+        e1 = torch.relu(z1) if mk is None else torch.relu(z1) * mk["h1"].double()
+        z2 = torch.addmm(p64["attention_net.2.bias"], e1, p64["attention_net.2.weight"].t())
+        e2 = torch.relu(z2) if mk is None else torch.relu(z2) * mk["h"].double()
+        for li, (z, e, hd, key) in enumerate(((z1, e1, dev["h1"][r0:r1], "h1"), (z2, e2, dev["h"][r0:r1], "h"))):
+            assert (hd.double() - e).abs().max().item() <= 1e-4 * max(e.abs().max().item(), 1.0), (name, b, key)
+            f = (hd > 0) != (z > 0)
+            if mk is not None:
+                f &= mk[key] > 0
+            if f.any():
+                assert z[f].abs().max().item() <= 2e-5 * z.abs().max().item(), f"{name}: slide {b} {key}: a mask differs at a pre-activation that is not round-off"
+            flips[li] += int(f.sum())
+        del z1, z2, e1, e2
+        for dt, tot, pp in ((torch.float64, tot64, p64), (torch.float32, tot32, params)):
+            s_ = orc.Saved(x=x.to(dt), h1=dev["h1"][r0:r1].to(dt), h=dev["h"][r0:r1].to(dt), p=dev["p"][r0:r1].to(dt), a_raw=dev["a_raw"][r0:r1].to(dt),
+                           m=None, mcat=None, sex=sx.to(dt), masks=None if mk is None else {k: v.to(dt) for k, v in mk.items()})
+            s_.m = orc.softmax_pool(s_.a_raw, s_.h)
+            s_.mcat, lg, _, _, sl, _, _ = orc.heads_fwd(s_.m, s_.sex, pp["classifier.weight"], pp["classifier.bias"], pp["site_classifier.weight"],
+                                                         pp["site_classifier.bias"])
+            dl, ds = orc.loss_grad(lg, lb, sl, st)
+            gb = orc.backward(pp, s_, dl, ds)
+            for k in tot:
+                tot[k] += gb[k].double() / B
+    rows = offs[-1]
+    assert flips[0] + flips[1] <= max(8, rows // 5000), (name, flips)      # a handful per 10^8 elements on random bags, never a pattern
+    for slot, key in SLOT2KEY.items():
+        noise = (tot32[key] - tot64[key]).abs().max().item()
+        assert_grad_close(grads[slot], tot64[key], 2e-5, grad_scale(tot64, key), what=f"{name}: {key} ({flips[0]}+{flips[1]} legit mask differences)",
+                          floor=(32.0 if slot in ("ba", "bb", "bc") else 10.0) * noise)
+    return tot32, tot64, flips

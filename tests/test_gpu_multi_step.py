@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import toad_oracle as orc
-from tests.helpers import SLOT2KEY, assert_grad_close, assert_grad_close_or_few_flips, grad_scale
+from tests.helpers import SLOT2KEY, assert_grad_close, assert_grad_close_or_few_flips, check_batch_against_oracle, grad_scale
 
 pytestmark = pytest.mark.gpu
 
@@ -95,6 +95,90 @@ def test_batch_gradient_is_the_sum_of_the_slide_gradients(cuda, lens):
         offs.append(offs[-1] + n)
     ops.mil_multi_step(w, g4, 0.0, xcat, sex, label, site, 0.75 / B, 0.25 / B, offsets=offs)
     assert all(torch.equal(g2[k], g4[k]) for k in ops.STEP_SLOTS)
+
+
+def _step_workspace_activations(n, nb, c, d, dev):
+    """Test-only view of what toad_mil_multi_step_f32 left in the cached step workspace: the forward arena sits at the aligned base of the
+    workspace (csrc/step.hip: align_base + arena_layout), so H1, H, P and A_raw of the CONCATENATION can be read back after the call."""
+    import ctypes
+    from toad_amd import _lib, ops
+    lib = _lib.load()
+    ws = ops._ws(int(lib.toad_mil_multi_ws_bytes(n, nb, c, d)), dev, "step")
+    base = (-ws.data_ptr()) % int(lib.toad_mil_buffer_align(n))
+    offs = (ctypes.c_int64 * len(ops.ARENA_SLOTS))()
+    _lib.check(lib.toad_mil_arena_layout(n, c, d, offs), "toad_mil_arena_layout")
+    off = dict(zip(ops.ARENA_SLOTS, (base + int(o) for o in offs)))
+
+    def view(name, cols):
+        return ws[off[name]:off[name] + n * cols * 4].view(torch.float32).view(n, cols)
+    return view("h1", 512), view("h", 512), view("p", 2 * d), view("a_raw", 2)
+
+
+# The shapes bench.py --config 4 actually calls (two 50,000-patch slides per toad_mil_multi_step_f32 = 100,000 concatenated rows) and their
+# neighbours. Everything above 40,000 rows switches on three code paths no smaller batch reaches:
+#   (a) staggered workgroup starts of the persistent NT GEMMs (csrc/gemm_f32.hip launch_nt_h2: es.stagger for launches of >= 512 tiles);
+#   (b) dP's abs-max array taken from the per-row |dP| bound the batched pool backward leaves in dZ1's buffer, folded 256 rows per slot
+#       (csrc/step.hip: launch_pool_bwd_batch(..., w.amax_dP, w.dZ1, N)) - slide boundaries off the 256-row grid matter here;
+#   (c) the attention dgrad on the one-bit ReLU image with a materialised addend (gemm_nt_h2_big_kernel<true, false, 2, 0>).
+# Reference semantics: utils/core_utils_mtl_concat.py:200-234, one forward / loss / backward per slide; the batch gradient is their sum.
+BIG_BATCHES = [("config4_pair", [50000, 50000], 0.0), ("batch_rows_limit", [65536, 65536], 0.0), ("off_grid_boundaries", [50000, 30001, 20000], 0.0),
+               ("dropout_70k_rows", [40000, 30001], 0.25)]
+
+
+@pytest.mark.parametrize("name,lens,drop_p", BIG_BATCHES, ids=[b[0] for b in BIG_BATCHES])
+def test_config4_shape_batches_match_the_oracle(cuda, name, lens, drop_p):
+    """Value check of the ragged multi-slide step at config 4's own call shape (see BIG_BATCHES). Per slide: logits, site logits and loss against
+    the oracle's fp32 forward (1e-4, the north star's bound); H1 / H of the concatenation against the exact fp64 forward (1e-4 of their abs-max),
+    every ReLU-mask difference from the exact forward shown to be legitimate (pre-activation within round-off of zero) and rare; all 14 gradients
+    against the SUM over slides of the oracle's fp64 backward evaluated on the device's own activations (identical masks, so no flip allowance is
+    needed): 2e-5 of each gradient's own scale, plus the measured fp32 noise of the same backward for the cancellation-dominated ones. With
+    drop_p the device's masks are exported (toad_dropout_mask_f32) and fed to the oracle, as in the small-batch dropout test."""
+    from toad_amd import functional as F_, ops
+    model, params = _model(cuda, seed=len(lens) + 40, dropout=drop_p > 0)
+    if drop_p > 0:                                            # dropout=True shifts the state-dict indices; the oracle uses the dropout=False names
+        rename = {"attention_net.3.": "attention_net.2.", "attention_net.6.": "attention_net.4."}
+        params = {next((b + k[len(a):] for a, b in rename.items() if k.startswith(a)), k): v for k, v in params.items()}
+    w = {k: v.detach() for k, v in model._weights().items()}
+    slides = _slides(lens, seed=77)
+    B, ntot, d = len(lens), sum(lens), w["wc"].shape[1]
+    xcat = torch.cat([s[0] for s in slides], 0).to(cuda)
+    sex = torch.cat([s[1] for s in slides]).to(cuda); label = torch.cat([s[2] for s in slides]).to(cuda); site = torch.cat([s[3] for s in slides]).to(cuda)
+    offs = [0]
+    for n in lens:
+        offs.append(offs[-1] + n)
+    seed = 20260927
+    g = {k: torch.zeros_like(w[k]) for k in ops.STEP_SLOTS}
+    loss, logits, slog = ops.mil_multi_step(w, g, 0.0, xcat, sex, label, site, 0.75 / B, 0.25 / B, drop_p=drop_p, seed=seed, want_logits=True, offsets=offs)
+    torch.cuda.synchronize()
+    h1_d, h_d, p_d, a_d = (t.cpu() for t in _step_workspace_activations(ntot, B, C, d, cuda))
+    loss, logits, slog = loss.cpu(), logits.cpu(), slog.cpu()
+    G, mask64 = 0x9E3779B97F4A7C15, 0xFFFFFFFFFFFFFFFF
+    masks = None
+    if drop_p > 0:
+        s1, s2, sa, sb = F_.drop_seeds(seed)
+        mk_h1 = ops.dropout_mask(ntot * 512, drop_p, s1, cuda).reshape(ntot, 512).cpu()
+        mk_h = ops.dropout_mask(ntot * 512, drop_p, s2, cuda).reshape(ntot, 512).cpu()
+        masks = [{"h1": mk_h1[offs[b]:offs[b + 1]], "h": mk_h[offs[b]:offs[b + 1]],
+                  "a": ops.dropout_mask(lens[b] * d, drop_p, (sa + 2 * b * G) & mask64, cuda).reshape(lens[b], d).cpu(),
+                  "b": ops.dropout_mask(lens[b] * d, drop_p, (sb + 2 * b * G) & mask64, cuda).reshape(lens[b], d).cpu()} for b in range(B)]
+
+    def full(gd):
+        o = dict(gd); o["wa"], o["wb"], o["ba"], o["bb"] = gd["wab"][:d], gd["wab"][d:], gd["bab"][:d], gd["bab"][d:]
+        return o
+    got = full(g)
+    tot32, tot64, flips = check_batch_against_oracle(name, params, slides, offs, dict(h1=h1_d, h=h_d, p=p_d, a_raw=a_d, logits=logits, site_logits=slog, loss=loss),
+                                                     {s_: got[s_].cpu() for s_ in SLOT2KEY}, masks)
+    if drop_p == 0.0:
+        # and against B one-slide steps of the same kernels, on the ten gradients no ReLU mask reaches (the two routes scale their GEMM operands per
+        # 256-row block of different row ranges, so a pre-activation at round-off of zero may fall either way between them)
+        g1 = {k: torch.zeros_like(w[k]) for k in ops.STEP_SLOTS}
+        for i in range(B):
+            ops.mil_step(w, g1, 0.0 if i == 0 else 1.0, xcat[offs[i]:offs[i + 1]], sex[i:i + 1], label[i:i + 1], site[i:i + 1], 0.75 / B, 0.25 / B)
+        got1 = full(g1)
+        for slot, key in SLOT2KEY.items():
+            if slot not in ("w1", "b1", "w2", "b2"):
+                noise = (tot32[key] - tot64[key]).abs().max().item()
+                assert_grad_close(got[slot], got1[slot], 5e-5, grad_scale(tot64, key), what=f"{name}: batch vs per-slide: {key}", floor=32.0 * noise)
 
 
 def test_dp_step_batches_small_slides(cuda):

@@ -110,3 +110,45 @@ def test_oracle_dropout_backward_matches_autograd_and_reference_dropout_semantic
     for k in orc.PARAM_KEYS:
         ref = params[k].grad
         assert (g[k] - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1.0), k
+
+
+@pytest.mark.parametrize("drop", [False, True])
+def test_batch_checker_accepts_a_correct_batch_and_rejects_a_wrong_gradient(drop):
+    """Self-test of tests/helpers.py::check_batch_against_oracle (the checker of the config-4-shape GPU tests) without a GPU: fed the oracle's
+    own fp32 forward activations and the autograd gradient of the summed per-slide losses (utils/core_utils_mtl_concat.py:200-234 semantics) it
+    passes; with one gradient off by 1e-3 of its scale, or one slide's rows of H shifted, it fails."""
+    from tests.helpers import SLOT2KEY, check_batch_against_oracle
+    torch.manual_seed(11)
+    lens = [300, 77, 513]
+    B = len(lens)
+    base = orc.xavier_params(18, seed=9)
+    for k in base:
+        if base[k].dim() == 1:
+            base[k].normal_(0, 0.05)
+    params = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+    slides, masks, offs = [], ([] if drop else None), [0]
+    for i, n in enumerate(lens):
+        slides.append((torch.randn(n, 1024), torch.tensor([float(i % 2)]), torch.tensor([(5 * i) % 18]), torch.tensor([i % 2])))
+        offs.append(offs[-1] + n)
+        if drop:
+            masks.append({k: (torch.rand(n, w) >= 0.25).float() / 0.75 for k, w in (("h1", 512), ("h", 512), ("a", 384), ("b", 384))})
+    dev = {k: [] for k in ("h1", "h", "p", "a_raw", "logits", "site_logits", "loss")}
+    total = 0.0
+    for b, (x, sx, lb, st) in enumerate(slides):
+        out, sv = orc.forward(params, x, sx, masks=None if masks is None else masks[b])
+        loss = orc.loss_fn(out["logits"], lb, out["site_logits"], st)
+        total = total + loss / B
+        for k, v in (("h1", sv.h1), ("h", sv.h), ("p", sv.p), ("a_raw", sv.a_raw), ("logits", out["logits"]), ("site_logits", out["site_logits"])):
+            dev[k].append(v.detach())
+        dev["loss"].append(torch.stack([loss.detach() / B] * 3)[None])
+    total.backward()
+    dev = {k: torch.cat(v, 0) for k, v in dev.items()}
+    grads = {s: params[k].grad.clone() for s, k in SLOT2KEY.items()}
+    _, _, flips = check_batch_against_oracle("selftest", base, slides, offs, dev, grads, masks)
+    assert flips[0] + flips[1] <= 2
+    bad = dict(grads); bad["w2"] = grads["w2"] + 1e-3 * grads["w2"].abs().max()
+    with pytest.raises(AssertionError):
+        check_batch_against_oracle("selftest", base, slides, offs, dev, bad, masks)
+    bad_dev = dict(dev); bad_dev["h"] = dev["h"].clone(); bad_dev["h"][offs[1]:offs[2]] += 1e-2
+    with pytest.raises(AssertionError):
+        check_batch_against_oracle("selftest", base, slides, offs, bad_dev, grads, masks)
