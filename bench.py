@@ -105,17 +105,29 @@ def _cpu_name() -> str:
     return "unknown"
 
 
-POOL_TRAFFIC_FILE = "r04_pool_traffic.json"     # re-measured whenever the pool kernels change (tools/pmc_pool_traffic.sh writes it)
+POOL_TRAFFIC_FILE = "r05_pool_traffic.json"     # written by tools/pool_traffic_json.py from the PMC passes of `tools/gpu_run.sh TAG traffic`
+POOL_KERNEL_SOURCES = ("toad_amd/csrc/gated_pool.hip", "toad_amd/csrc/common.h")
+
+
+def pool_kernel_sha() -> str:
+    """sha256 over the sources the pool kernels are compiled from: what ties a committed traffic measurement to a kernel build."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in POOL_KERNEL_SOURCES:
+        with open(os.path.join(REPO, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def measured_pool_traffic(n: int):
-    """HBM bytes per launch of the fused pool forward from THIS round's committed rocprofv3 PMC passes
-    (profiles/r03_pool_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the gfx950 guide prescribes
-    for 16-B/lane streaming loads). Only valid for the N and the kernel build it was measured at; None (JSON null) otherwise."""
+    """HBM bytes per launch of the fused pool forward from THIS round's committed rocprofv3 PMC passes (profiles/r05_pool_traffic.json: separate
+    FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the gfx950 guide prescribes for 16-B/lane streaming loads). The file records the sha256
+    of the pool kernels' sources at measurement time: the figure is reported only for that N and while those sources are unchanged, else None
+    (JSON null) - an edit to the pool kernels silently invalidates nothing."""
     try:
         with open(os.path.join(REPO, "profiles", POOL_TRAFFIC_FILE)) as f:
             t = json.load(f)
-        if int(t["patches"]) == int(n):
+        if int(t["patches"]) == int(n) and t.get("kernel_source_sha256") == pool_kernel_sha():
             return float(t["pool_fwd_hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass

@@ -364,8 +364,11 @@ int toad_mil_step_x16_f32(const float *const *params, float *const *grads, float
  * (utils/core_utils_mtl_concat.py:231) - are a third of a step's flops. toad_bag_prepare_f32 converts the fp32 bag X [N,K] ONCE,
  * at ingest, into the form those products consume directly: its two fp16 pieces (x * 2^k = h + m, one exponent k per block of 256
  * rows) stored plane-tiled in the GEMMs' LDS stage order (csrc/gemm_pt.inc). Same 4 bytes per element as fp32 (the caller may then
- * drop the fp32 copy), bitwise the results of the fp32 calls (the same pieces, products and accumulation order - only nobody has to
- * re-derive the pieces every step), no per-step abs-max pass over the bag.
+ * drop the fp32 copy), no per-step abs-max pass over the bag. Agreement with the fp32 calls: BITWISE when the fp32 call is given the
+ * same abs-max array (x_amax != NULL: the same pieces, products and accumulation order); since ABI 10 an fp32 call with x_amax == NULL
+ * scales a raw bag inside the first GEMM from each tile's first 32 columns with 3 bits of head-room (gemm_h2.inc AMODE 3), so the two
+ * routes then differ in the operand exponent only: <= 5e-6 of each result tensor's scale (tests/test_gpu_pt.py ROUTE_TOL). Either route
+ * is bitwise deterministic run to run.
  *   planes : toad_bag_planes_bytes(N, K) bytes, 16-byte aligned; amax : toad_amax_floats(N) floats (the bag's abs-max array).
  * The *_xp_* calls are toad_mil_{fwd,bwd,step}_f32 with (Xp, x_amax) in place of X; dX is not available (the bag is data). */
 size_t toad_bag_planes_bytes(int64_t N, int64_t K);

@@ -10,7 +10,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("TOAD_HIP_LIB", os.path.join(_HERE, "libtoad_hip.so"))   # override: kernel A/B builds only
+LIB_PATH = os.path.join(_HERE, "libtoad_hip.so")      # the one library the product loads (A/B builds: tools/ab/select_lib.py rebinds this in the TOOL's process)
 ABI_VERSION = 12
 
 P, I64, I, F, SZ, U64 = c_void_p, c_int64, c_int, c_float, c_size_t, c_uint64

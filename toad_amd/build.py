@@ -28,8 +28,8 @@ def _stale(obj: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "") -> str:
-    """Build libtoad_hip{tag}.so. `defines` / `tag` build an experiment variant next to the shipped library (tools/ab/README.md; select it
-    at run time with TOAD_HIP_LIB=<path>); the sources under csrc/ carry no variant switches of their own."""
+    """Build libtoad_hip{tag}.so. `defines` / `tag` build an experiment variant next to the shipped library (tools/ab/README.md; the measurement tools select it
+    through tools/ab/select_lib.py, the product's loader never does); the sources under csrc/ carry no variant switches of their own."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     lib = LIB.replace(".so", tag + ".so")
     objs = []

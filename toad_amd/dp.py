@@ -90,8 +90,11 @@ def hip_batch_grad(model, grads: Dict[str, torch.Tensor], slides: Sequence[Slide
 class SlideShardedDP:
     def __init__(self, model, optimizer_factory: Callable[[Sequence[torch.nn.Parameter]], torch.optim.Optimizer],
                  process_group=None, slide_grad_fn: Optional[Callable] = None, broadcast_from: int = 0,
-                 always_reduce: bool = False):
-        """``always_reduce``: issue the gradient all-reduce whenever a process group exists, also at world size 1 (a sum over one
+                 always_reduce: bool = False, batch_max_patches: Optional[int] = None):
+        """``batch_max_patches``: slides of at most this many patches are batched into one ragged multi-slide call (default
+        ``BATCH_MAX_PATCHES``; 0 = never: every slide takes the per-slide call, whose train-mode dropout masks and operand scales are
+        those of the slide alone).
+        ``always_reduce``: issue the gradient all-reduce whenever a process group exists, also at world size 1 (a sum over one
         rank: the values do not change, but the RCCL communicator and its kernel run on the launch stream exactly as they do at
         N > 1 - the single-GPU proof of the collective path, tests/test_gpu_nccl_world1.py and bench.py's allreduce_us)."""
         self.model = model
@@ -136,6 +139,7 @@ class SlideShardedDP:
             self._flat_adam = None
             self.optimizer = optimizer_factory([self.flat_param])
         self.slide_grad_fn = slide_grad_fn or hip_slide_grad
+        self.batch_max_patches = self.BATCH_MAX_PATCHES if batch_max_patches is None else int(batch_max_patches)
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -166,7 +170,7 @@ class SlideShardedDP:
                 self.zero_grad()
             return []
         scale = 1.0 / float(global_slides)
-        small = lambda s: torch.is_tensor(s[0]) and 0 < s[0].shape[0] <= self.BATCH_MAX_PATCHES    # noqa: E731
+        small = lambda s: torch.is_tensor(s[0]) and 0 < s[0].shape[0] <= self.batch_max_patches    # noqa: E731
         if batched is None:
             batched = self.slide_grad_fn is hip_slide_grad and len(slides) > 1 and sum(1 for s in slides if small(s)) > 1
         if batched:

@@ -585,6 +585,9 @@ def mil_multi_step(w, grads, beta: float, bags, sex, label, site, w_cls: float =
         if len(ev_objs) == 18:
             for i, name in enumerate(_GEMM_EVENT_NAMES):
                 _TIMING.setdefault(name, []).append((ev_objs[2 + 2 * i], ev_objs[3 + 2 * i]))
+            # whole-call bucket from the events the library already records: first GEMM's start .. the deferred weight-gradient reduction's end
+            # (the weight split launch in front of the first GEMM, ~6 us, is outside it; no extra event packets on the stream)
+            _TIMING.setdefault("mil_multi_step", []).append((ev_objs[2], ev_objs[17]))
     return loss, logits, slog
 
 

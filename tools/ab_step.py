@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time
 import torch
+import tools.ab.select_lib as _sel      # TOAD_HIP_LIB=<variant.so> is honoured HERE, not by the product's loader
 from toad_amd import TOAD_fc_mtl_concat, ops
 from toad_amd.dp import SlideShardedDP
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
@@ -35,5 +36,5 @@ def mean(lst): return sum(a.elapsed_time(b) for a, b in lst) / len(lst) * 1e3
 f, w, d = T["gemm_fwd"], T["gemm_wgrad"], T["gemm_dgrad"]
 row = {"fwd1": mean(f[0::3]), "fwd2": mean(f[1::3]), "fwd_ab": mean(f[2::3]), "wgrad_ab": mean(w[0::3]), "dgrad_ab": mean(d[0::2]),
        "wgrad2": mean(w[1::3]), "dgrad2": mean(d[1::2]), "wgrad1": mean(w[2::3]), "pool_fwd": mean(T["pool_fwd"])}
-tag = (os.path.basename(os.environ.get("TOAD_HIP_LIB", "libtoad_hip.so")).replace("libtoad_hip", "").replace(".so", "") or "(shipped)") + "/" + os.environ.get("TOAD_BAG", "fp32")
+tag = _sel.TAG + "/" + os.environ.get("TOAD_BAG", "fp32")
 print(f"{tag:20s} step {plain:6.3f} ms | " + " ".join(f"{k} {v:6.1f}" for k, v in row.items()) + f" | gemm sum {sum(v for k, v in row.items() if k != 'pool_fwd'):7.1f}", flush=True)
