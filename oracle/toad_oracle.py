@@ -92,6 +92,14 @@ def closed_form_bag(n: int, l0: int = 1024, scale: float = 1.0, kind: str = "wav
     return torch.from_numpy((x * scale).astype(np.float32))
 
 
+def random_bag(n: int, seed: int, l0: int = 1024) -> torch.Tensor:
+    """N(0,1) bag [n, l0] from numpy's PCG64 stream (bit-stable across platforms and numpy versions, unlike torch's CPU generator across
+    torch versions): the second golden family (synthetic bags are N(0,1)). Pre-activations of a random bag are spread
+    continuously, so - unlike the closed-form cos/sin bags, which park some within fp32 round-off of zero - ReLU-mask flips between two
+    correct fp32 implementations are rare (expected ~0.7 per 10^7 mask elements)."""
+    return torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal((n, l0), dtype=np.float32))
+
+
 # --------------------------------------------------------------------------------------
 # Forward, op for op as the reference runs it
 # --------------------------------------------------------------------------------------

@@ -13,7 +13,8 @@ def case_inputs(golden, name):
     n, c, sex, label, site, scale, equal = golden[name + "/meta"]
     n, c = int(n), int(c)
     params = orc.closed_form_params(c)
-    x = orc.closed_form_bag(n, 1024, float(scale), "equal" if equal > 0.5 else "wave")
+    kind = {0: "wave", 1: "equal", 2: "randn"}[int(round(float(equal)))]        # meta[6]: bag family (oracle/pin_against_reference.py KIND_CODE)
+    x = orc.random_bag(n, 1000 + n) if kind == "randn" else orc.closed_form_bag(n, 1024, float(scale), kind)
     return dict(n=n, c=c, params=params, x=x, sex=torch.tensor([float(sex)]),
                 label=torch.tensor([int(label)]), site=torch.tensor([int(site)]))
 
@@ -193,10 +194,11 @@ def check_trunk_grads_vs_golden_blocks(golden, name, grads, x, flips1, flips2):
     u2 = set(int(j) for j in flips2[:, 1].tolist()) if len(flips2) else set()
     checked = 0
     # ---- layer 2: rows / entries outside the flipped units
+    blk = torch.from_numpy(golden[pre + "grad_block_rows"]).long()             # output units (rows of dW1 / dW2) the fixture carries
     g2 = grads[w2k].detach().cpu().double()
     ref2 = torch.from_numpy(golden[pre + "grad_block64/" + w2k]).double()
-    rows2 = [r for r in range(ref2.shape[0]) if r not in u2]
-    e2 = (g2[:ref2.shape[0]] - ref2)[rows2]
+    rows2 = [i for i, r in enumerate(blk.tolist()) if r not in u2]
+    e2 = (g2[blk] - ref2)[rows2]
     assert float(e2.abs().max()) <= tol_of(w2k), f"{name}: dW2 rows without a flipped unit deviate from the reference by {float(e2.abs().max()):.3e} (tol {tol_of(w2k):.3e})"
     checked += len(rows2)
     gb2 = grads[b2k].detach().cpu().double()
@@ -206,10 +208,10 @@ def check_trunk_grads_vs_golden_blocks(golden, name, grads, x, flips1, flips2):
     # ---- layer 1: block rows outside the layer-1 flipped units, minus their component along the layer-2 flipped patches' feature rows
     g1 = grads[w1k].detach().cpu().double()
     ref1 = torch.from_numpy(golden[pre + "grad_block64/" + w1k]).double()
-    rows1 = [r for r in range(ref1.shape[0]) if r not in u1]
-    e1 = (g1[:ref1.shape[0]] - ref1)[rows1]
+    rows1 = [i for i, r in enumerate(blk.tolist()) if r not in u1]
+    e1 = (g1[blk] - ref1)[rows1]
     gb1 = grads[b1k].detach().cpu().double()
-    eb1 = (gb1 - torch.from_numpy(golden[pre + "grad_block64/" + b1k]).double())[rows1]
+    eb1 = (gb1 - torch.from_numpy(golden[pre + "grad_block64/" + b1k]).double())[blk][rows1]
     patches = sorted(set(int(n) for n in flips2[:, 0].tolist())) if len(flips2) else []
     if patches:
         xs = x[patches].double()                                  # [k, 1024]

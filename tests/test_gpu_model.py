@@ -9,7 +9,7 @@ from tests.helpers import (LAYER2_KEYS, MASK_FREE_KEYS, SLOT2KEY, assert_grad_cl
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["n0", "n1", "n2", "n63", "n64", "n65", "n256", "n777", "n777_c2", "n1024_sat", "n300_equal", "n10000", "n100000"]
+CASES = ["n0", "n1", "n2", "n63", "n64", "n65", "n256", "n777", "n777_c2", "n1024_sat", "n300_equal", "n10000", "n100000", "r256", "r10000", "r100000"]
 FLIPS = {}              # case -> (legitimate ReLU-mask flips in layer 1, in layer 2), filled by test_module_matches_reference_golden
 # Of the 13 golden cases, at most this many may have ANY gradient compared with something other than the reference's golden values.
 # Measured on MI355X (round 3, gpurun_out/golden_flip_cases.json): 6 - n256 (0 flips in layer 1, 1 in layer 2), n777 (1, 1), n777_c2 (1, 1),
@@ -17,6 +17,11 @@ FLIPS = {}              # case -> (legitimate ReLU-mask flips in layer 1, in lay
 # pre-activations within fp32 round-off of zero. In those cases the TEN mask-free gradients are still held to the golden values; only the four
 # trunk gradients (dW1, db1, dW2, db2) go to the fp64 backward on the device's own activations. The other 7 cases compare all 14.
 MAX_FLIP_CASES = 7
+# Round 5: the second golden family, N(0,1) bags (r256 / r10000 / r100000, oracle/pin_against_reference.py): no pre-activation is parked at
+# round-off of zero, a flip needs |z| < ~1e-7 at |z| ~ 1 (expected 0.02 / 0.7 / 7 flipped mask elements of 2.6e5 / 1e7 / 1e8), so the two smaller
+# cases compare all 14 gradients element-wise with the reference's values on (almost) every run; r100000 keeps the flip machinery.
+RANDN_CASES = ("r256", "r10000", "r100000")
+MAX_FLIP_CASES_RANDN = 2
 
 
 def _model(c, params, cuda):
@@ -55,11 +60,11 @@ def test_module_matches_reference_golden(cuda, golden, name):
         pos1, pos2 = relu_flip_positions(ci["params"], ci["x"], sv.h1, sv.h)
         f1, f2 = int(pos1.shape[0]), int(pos2.shape[0])
         # H1 / H themselves against the reference's activations (forward hooks on its ReLU modules) at the BASELINE sizes
-        assert check_activations_vs_golden(golden, name, sv.h1, sv.h) == (name in ("n10000", "n100000"))
+        assert check_activations_vs_golden(golden, name, sv.h1, sv.h) == (name in ("n10000", "n100000", "r10000", "r100000"))
         # the four trunk gradients against the REFERENCE's fp64 matrices, flips or not: what the known flipped mask elements cannot
         # explain must match the reference (tests/helpers.py); the device-activation comparison below stays as the all-rows check
         rows = check_trunk_grads_vs_golden_blocks(golden, name, grads, ci["x"], pos1, pos2)
-        assert (rows > 0) == (name in ("n256", "n777", "n777_c2", "n1024_sat", "n10000", "n100000")), (name, rows)
+        assert (rows > 0) == (name in ("n256", "n777", "n777_c2", "n1024_sat", "n10000", "n100000") + RANDN_CASES), (name, rows)
     FLIPS[name] = (f1, f2)
     n_flips = f1 + f2
     # against the REFERENCE's golden gradients: all 14 when no mask flipped; otherwise every gradient a flip cannot reach (the ten
@@ -94,14 +99,15 @@ def test_golden_gradient_comparison_rarely_leaves_the_golden_values():
     try:
         os.makedirs("gpurun_out", exist_ok=True)
         with open("gpurun_out/golden_flip_cases.json", "w") as f:
-            json.dump({"cases": len(FLIPS), "flipped": flipped, "max_allowed": MAX_FLIP_CASES}, f)
+            json.dump({"cases": len(FLIPS), "flipped": flipped, "max_allowed_closed_form": MAX_FLIP_CASES, "max_allowed_randn": MAX_FLIP_CASES_RANDN}, f)
     except OSError:
         pass
-    assert len(flipped) <= MAX_FLIP_CASES, flipped
+    assert sum(1 for k in flipped if k not in RANDN_CASES) <= MAX_FLIP_CASES, flipped
+    assert sum(1 for k in flipped if k in RANDN_CASES) <= MAX_FLIP_CASES_RANDN and sum(sum(flipped.get(k, (0, 0))) for k in ("r256", "r10000")) <= 3, flipped
     assert all(sum(v) <= 64 for v in flipped.values()), flipped     # a handful of boundary elements, not a systematic difference
 
 
-@pytest.mark.parametrize("name", ["n777", "n1024_sat", "n10000", "n100000"])
+@pytest.mark.parametrize("name", ["n777", "n1024_sat", "n10000", "n100000", "r100000"])
 def test_backward_chain_tight_with_identical_relu_masks(cuda, golden, name):
     """Flip-free check of the whole backward chain: the oracle's hand-written backward is run on
     the activations the GPU forward saved (so ReLU masks are identical on both sides); what is left

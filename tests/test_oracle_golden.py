@@ -8,7 +8,7 @@ from oracle import toad_oracle as orc
 from tests.helpers import (case_inputs, check_activations_vs_golden, check_outputs_vs_golden, check_trunk_grads_vs_golden_blocks,
                            relu_flip_positions)
 
-SMALL = ["n1", "n2", "n63", "n64", "n65", "n256", "n777", "n777_c2", "n1024_sat", "n300_equal", "n10000"]
+SMALL = ["n1", "n2", "n63", "n64", "n65", "n256", "n777", "n777_c2", "n1024_sat", "n300_equal", "n10000", "r256", "r10000"]
 
 
 @pytest.mark.parametrize("name", SMALL)
@@ -21,7 +21,7 @@ def test_oracle_matches_reference_golden(golden, name):
     check_outputs_vs_golden(golden, name, out, loss, grads, atol=2e-5)
 
 
-@pytest.mark.parametrize("name", ["n256", "n777_c2", "n1024_sat", "n10000"])
+@pytest.mark.parametrize("name", ["n256", "n777_c2", "n1024_sat", "n10000", "r256", "r10000"])
 def test_trunk_gradient_blocks_keep_the_reference_as_comparand(golden, name):
     """The flip-tolerant comparison the GPU suite uses for dW1 / db1 / dW2 / db2 (tests/helpers.py), exercised here with the fp32 oracle
     standing in for the device: the oracle in fp32 is bitwise the reference in fp32, whose ReLU masks differ from the fp64 reference's
@@ -31,12 +31,12 @@ def test_trunk_gradient_blocks_keep_the_reference_as_comparand(golden, name):
     _, saved = orc.forward(ci["params"], ci["x"], ci["sex"])
     _, _, grads = orc.fwd_bwd(ci["params"], ci["x"], ci["sex"], ci["label"], ci["site"])
     p1, p2 = relu_flip_positions(ci["params"], ci["x"], saved.h1, saved.h)
-    assert check_trunk_grads_vs_golden_blocks(golden, name, grads, ci["x"], p1, p2) >= 200
-    assert check_activations_vs_golden(golden, name, saved.h1, saved.h) == (name == "n10000")
+    assert check_trunk_grads_vs_golden_blocks(golden, name, grads, ci["x"], p1, p2) >= 50       # of the 2 x 32 strided block rows
+    assert check_activations_vs_golden(golden, name, saved.h1, saved.h) == (name in ("n10000", "r10000"))
     # sensitivity: one wrong element in an unflipped row, or a rank-one error along a patch that did NOT flip, fails the check
     k1, k2 = "attention_net.0.weight", "attention_net.2.weight"
     flipped2 = set(int(j) for j in p2[:, 1].tolist())
-    row = next(r for r in range(100) if r not in flipped2)
+    row = next(r for r in golden[name + "/grad_block_rows"].tolist() if r not in flipped2)
     for key, delta in ((k2, None), (k1, "rank1")):
         bad = {k: v.clone() for k, v in grads.items()}
         sc = float(golden[name + "/grad_absmax/" + key])
