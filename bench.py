@@ -449,6 +449,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="headline run without the extra drop-in timing")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="config 4 only: log-normal slide lengths (same 64 x 50k = 3.2 M patches in total, sigma 0.7, seeded) dealt with "
+                         "dp.shard_by_length instead of 64 equal slides round robin - what a real cohort looks like (docs/README.md: 22k WSIs of very "
+                         "different size); per_rank.patches_per_step / step_ms then show the imbalance. Reported under its own metric name.")
     ap.add_argument("--single-device", action="store_true",
                     help="plumbing test only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     args = ap.parse_args()
@@ -497,7 +501,7 @@ def main():
         return
 
     from toad_amd import TOAD_fc_mtl_concat, ops
-    from toad_amd.dp import SlideShardedDP, shard_round_robin
+    from toad_amd.dp import SlideShardedDP, shard_by_length, shard_round_robin
 
     torch.manual_seed(1)                                   # main_mtl_concat.py:89 default seed
     model = TOAD_fc_mtl_concat(dropout=False, n_classes=C)
@@ -505,20 +509,31 @@ def main():
     model.train()
     dp = SlideShardedDP(model, {"lr": 1e-4, "weight_decay": 1e-5}, always_reduce=under_torchrun)      # get_optim defaults (main_mtl_concat.py:93-96), HIP flat Adam
 
+    ragged_lens = None
     if args.config == 4:
         n = args.patches or 50_000
         global_slides = 64
-        mine = shard_round_robin(global_slides, rank, world)           # slide i -> rank i mod G
+        if args.ragged:
+            import numpy as np
+            raw = np.random.Generator(np.random.PCG64(4)).lognormal(mean=0.0, sigma=0.7, size=global_slides)
+            ragged_lens = np.maximum(1024, np.round(raw / raw.sum() * global_slides * n)).astype(np.int64).tolist()
+            mine = shard_by_length(ragged_lens, rank, world)           # longest-processing-time greedy: cost ~ patches
+            lens = [ragged_lens[i] for i in mine]
+        else:
+            mine = shard_round_robin(global_slides, rank, world)       # slide i -> rank i mod G
+            lens = [n] * len(mine)
         # the rank's bags lie back to back in ONE resident buffer (what an ingest buffer filled slide after slide looks like): the ragged
         # multi-slide call takes consecutive bags as their own concatenation, without copying a row (ops._adjacent_rows)
-        pool = torch.empty((len(mine) * n, L0), device=dev, dtype=BAG_DTYPE)
+        pool = torch.empty((sum(lens), L0), device=dev, dtype=BAG_DTYPE)
         slides = [[]]
-        for s_, i in enumerate(mine):
-            bag, sex_, label_, site_ = make_slide(i, n, dev)
+        off = 0
+        for i, ni in zip(mine, lens):
+            bag, sex_, label_, site_ = make_slide(i, ni, dev)
             if getattr(bag, "is_prepared_bag", False):                 # --bag-format prepared: per-slide calls on prepared bags
                 slides[0].append((bag, sex_, label_, site_))
                 continue
-            view = pool[s_ * n:(s_ + 1) * n]
+            view = pool[off:off + ni]
+            off += ni
             view.copy_(bag)
             slides[0].append((view, sex_, label_, site_))             # the same 64 resident slides every step
             del bag
@@ -533,7 +548,7 @@ def main():
         slides = [[make_slide((rank * spr + s) * nbags + b, n, dev) for s in range(spr)] for b in range(nbags)]
         global_slides = spr * world
         scaling = "weak"
-    patches_per_rank_step = n * len(slides[0])
+    patches_per_rank_step = sum(int(sl[0].shape[0]) for sl in slides[0])
     prepared = BAG_PREPARED and args.bag_dtype == "fp32" and n >= 64
     batched = len(slides[0]) > 1 and n <= SlideShardedDP.BATCH_MAX_PATCHES and args.bag_dtype == "fp32" and not prepared
 
@@ -613,6 +628,9 @@ def main():
                   4: "slides/sec fwd+bwd, 64 slides x 50k patches per step, slide-sharded DP (BASELINE config 4)"}[args.config]
         if args.config == 0 and n != 100_000:
             metric = f"slides/sec fwd+bwd, {n}-patch x 1024-d bags"
+        if ragged_lens is not None:
+            metric = ("slides/sec fwd+bwd, 64 slides of LOG-NORMAL length (3.2 M patches in total, %d..%d per slide) per step, length-balanced "
+                      "slide-sharded DP (config 4 made ragged; not the BASELINE line)" % (min(ragged_lens), max(ragged_lens)))
         if args.bag_dtype == "fp16":
             metric += " STORED AS fp16 (not a BASELINE configuration)"
         if prepared:
@@ -643,7 +661,8 @@ def main():
             pool_t = tot_ms / calls * 1e-3
             calls_per_step = calls / args.steps                          # per-slide calls: slides per rank; ragged batch call: 1
             slides_per_call = len(slides[0]) / calls_per_step
-            pool_bytes = pool_fwd_bytes(n) * slides_per_call             # one launch pools every slide of the call (blockIdx.y = slide)
+            # one launch pools every slide of the call (blockIdx.y = slide); ragged slides: the bytes of this rank's rows, per call on average
+            pool_bytes = pool_fwd_bytes(n) * slides_per_call if ragged_lens is None else pool_fwd_bytes(patches_per_rank_step) / calls_per_step
             pool_bw = pool_bytes / pool_t
             out["roofline"] = {"bound": "hbm", "kernel": "gated_pool_fwd_kernel<2,3,4,true> + gated_pool_combine_kernel"
                                                          + (f" (batched launch: {slides_per_call:g} slides, blockIdx.y = slide)" if slides_per_call > 1 else ""),

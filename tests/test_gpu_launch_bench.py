@@ -61,3 +61,35 @@ def test_world_two_plumbing_on_one_gpu_over_gloo(cuda, extra, scaling, slides):
     assert pr["patches_per_step"][0] == pr["patches_per_step"][1]              # both configurations shard evenly over two ranks
     assert max(pr["step_ms"]) <= out["ms_per_step"] * 1.05                      # the line's time is the max over ranks (barrier included)
     assert out["value"] > 0 and abs(out["value"] - slides * 1e3 / out["ms_per_step"]) <= 1e-2 * out["value"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("extra,scaling,slides", [([], "weak", 8), (["--config", "4"], "strong", 64), (["--config", "4", "--ragged"], "strong", 64)],
+                         ids=["headline", "config4", "config4_ragged"])
+def test_world_eight_plumbing_on_one_gpu_over_gloo(cuda, extra, scaling, slides):
+    """The driver's 8-GPU launch shape on the one device a test box has: `bench.py --gpus 8` spawns eight ranks (toad_amd/launch.py), every rank
+    builds its shard (config 4: 8 of the 64 slides, two per ragged multi-slide call), steps with the gradient all-reduce inside, and rank 0
+    prints ONE JSON line with the per-rank attribution. `--single-device --backend gloo` is a plumbing switch (RCCL refuses eight ranks on one
+    GPU), never a measurement: the value is asserted to be self-consistent, not fast. `--ragged` deals 64 slides of log-normal length with
+    dp.shard_by_length: the patch counts per rank must balance to a few percent and cover all 3.2 M patches exactly once."""
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--single-device", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-dropin", "--sustain-seconds", "0"] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=860)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == scaling and out["steps"] == 2 and out["config"]["slides_per_step"] == slides
+    assert out["allreduce"]["world"] == 8 and out["allreduce"]["us"] > 0
+    pr = out["per_rank"]
+    assert len(pr["step_ms"]) == len(pr["allreduce_us"]) == len(pr["patches_per_step"]) == 8
+    if "--ragged" in extra:
+        assert sum(pr["patches_per_step"]) == pytest.approx(64 * 50000, rel=2e-3) and "LOG-NORMAL" in out["metric"]
+        assert max(pr["patches_per_step"]) <= 1.10 * min(pr["patches_per_step"]), pr["patches_per_step"]      # longest-processing-time greedy balances 64 slides over 8 ranks
+    else:
+        assert len(set(pr["patches_per_step"])) == 1 and pr["patches_per_step"][0] == (100000 if not extra else 8 * 50000)
+    assert max(pr["step_ms"]) <= out["ms_per_step"] * 1.05
+    assert out["value"] > 0 and abs(out["value"] - slides * 1e3 / out["ms_per_step"]) <= 1e-2 * out["value"]
+    for key in ("roofline", "roofline_mfma"):
+        assert 0 < out[key]["frac"] < 1, key
