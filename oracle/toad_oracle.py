@@ -92,6 +92,20 @@ def closed_form_bag(n: int, l0: int = 1024, scale: float = 1.0, kind: str = "wav
     return torch.from_numpy((x * scale).astype(np.float32))
 
 
+def random_params(n_classes: int, seed: int, size_arg: str = "big", bias_scale: float = 0.05) -> Dict[str, torch.Tensor]:
+    """Xavier-normal weights (utils/utils.py:150-154: std = sqrt(2 / (fan_in + fan_out))) and small non-zero biases from numpy's PCG64 stream
+    (bit-stable across platforms). The closed-form sine weights make layer 2's pre-activations 15x smaller than Xavier's (std 0.065), i.e.
+    15x more of them at round-off of zero; the second golden family uses these instead."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = {}
+    for k, shp in param_shapes(n_classes, size_arg).items():
+        if len(shp) == 2:
+            out[k] = torch.from_numpy((rng.standard_normal(shp) * math.sqrt(2.0 / (shp[0] + shp[1]))).astype(np.float32))
+        else:
+            out[k] = torch.from_numpy((rng.standard_normal(shp) * bias_scale).astype(np.float32))
+    return out
+
+
 def random_bag(n: int, seed: int, l0: int = 1024) -> torch.Tensor:
     """N(0,1) bag [n, l0] from numpy's PCG64 stream (bit-stable across platforms and numpy versions, unlike torch's CPU generator across
     torch versions): the second golden family (synthetic bags are N(0,1)). Pre-activations of a random bag are spread

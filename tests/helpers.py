@@ -12,9 +12,9 @@ SLOT2KEY = dict(zip(
 def case_inputs(golden, name):
     n, c, sex, label, site, scale, equal = golden[name + "/meta"]
     n, c = int(n), int(c)
-    params = orc.closed_form_params(c)
     kind = {0: "wave", 1: "equal", 2: "randn"}[int(round(float(equal)))]        # meta[6]: bag family (oracle/pin_against_reference.py KIND_CODE)
     x = orc.random_bag(n, 1000 + n) if kind == "randn" else orc.closed_form_bag(n, 1024, float(scale), kind)
+    params = orc.random_params(c, 2000 + n) if kind == "randn" else orc.closed_form_params(c)
     return dict(n=n, c=c, params=params, x=x, sex=torch.tensor([float(sex)]),
                 label=torch.tensor([int(label)]), site=torch.tensor([int(site)]))
 

@@ -17,9 +17,12 @@ FLIPS = {}              # case -> (legitimate ReLU-mask flips in layer 1, in lay
 # pre-activations within fp32 round-off of zero. In those cases the TEN mask-free gradients are still held to the golden values; only the four
 # trunk gradients (dW1, db1, dW2, db2) go to the fp64 backward on the device's own activations. The other 7 cases compare all 14.
 MAX_FLIP_CASES = 7
-# Round 5: the second golden family, N(0,1) bags (r256 / r10000 / r100000, oracle/pin_against_reference.py): no pre-activation is parked at
-# round-off of zero, a flip needs |z| < ~1e-7 at |z| ~ 1 (expected 0.02 / 0.7 / 7 flipped mask elements of 2.6e5 / 1e7 / 1e8), so the two smaller
-# cases compare all 14 gradients element-wise with the reference's values on (almost) every run; r100000 keeps the flip machinery.
+# Round 5: the second golden family, N(0,1) bags with Xavier-normal weights (r256 / r10000 / r100000, oracle/pin_against_reference.py): no
+# pre-activation is parked at round-off of zero and both layers' pre-activations have std ~1, so a flip needs |z| < ~1e-7: expected 0.02 / 0.7 / 7
+# flipped mask elements of 2.6e5 / 1e7 / 1e8. r256 compares all 14 gradients element-wise with the reference's values on every run, r10000 on most;
+# r100000 keeps the flip machinery (1e8 mask elements cannot all be further than round-off from zero). The closed-form weights of the first
+# family make layer 2's pre-activations 15x smaller (std 0.065), which is why it flips so much more (measured with N(0,1) bags on those
+# weights: r10000 (0, 12), r100000 (5, 82); the CPU oracle's own fp32 run: r10000 (0, 6)).
 RANDN_CASES = ("r256", "r10000", "r100000")
 MAX_FLIP_CASES_RANDN = 2
 
@@ -103,7 +106,7 @@ def test_golden_gradient_comparison_rarely_leaves_the_golden_values():
     except OSError:
         pass
     assert sum(1 for k in flipped if k not in RANDN_CASES) <= MAX_FLIP_CASES, flipped
-    assert sum(1 for k in flipped if k in RANDN_CASES) <= MAX_FLIP_CASES_RANDN and sum(sum(flipped.get(k, (0, 0))) for k in ("r256", "r10000")) <= 3, flipped
+    assert sum(1 for k in flipped if k in RANDN_CASES) <= MAX_FLIP_CASES_RANDN and "r256" not in flipped and sum(flipped.get("r10000", (0, 0))) <= 4, flipped
     assert all(sum(v) <= 64 for v in flipped.values()), flipped     # a handful of boundary elements, not a systematic difference
 
 
@@ -289,10 +292,13 @@ def test_non_default_stream_and_autograd_thread(cuda):
         assert all(torch.equal(a, b) for a, b in zip(gs, ref_grads))
 
 
-@pytest.mark.parametrize("shape", [None, (512, 384, 2), (200, 100, 3), (768, 128, 4), (640, 512, 1), (1024, 256, 2)])
+@pytest.mark.parametrize("shape", [None, (512, 384, 2), (200, 100, 3), (768, 128, 4), (640, 512, 1), (1024, 256, 2),
+                                   (2048, 640, 5), (100, 30, 7), (1536, 1100, 1), (36, 516, 9)])
 def test_attn_net_gated_standalone(cuda, shape):
     """Attn_Net_Gated with its constructor defaults (L=1024, D=256, n_tasks=1; model_toad.py:19) and with other (L, D, n_tasks) the
-    constructor accepts: forward scores and all gradients (parameters and input) against autograd on the oracle's formula."""
+    constructor accepts: forward scores and all gradients (parameters and input) against autograd on the oracle's formula. The last four
+    shapes lie OUTSIDE the pool kernels' covering instantiation (L > 1024 or not a multiple of 8, D > 512 or not a multiple of 4, n_tasks > 4:
+    round 4 raised NotImplementedError there; the reference takes any) and run over column / task blocks with zero padding."""
     from toad_amd import Attn_Net_Gated
     torch.manual_seed(4)
     l, d, t = shape or (1024, 256, 1)

@@ -26,6 +26,7 @@ from . import functional as F_
 from . import ops
 
 _ALIGN = 64  # floats (256 B): every parameter starts 256-B aligned inside the flat buffer
+_M64 = 0xFFFFFFFFFFFFFFFF
 
 
 def initialize_weights(module: nn.Module) -> None:
@@ -52,36 +53,80 @@ def _draw_dropout(active: bool):
     return F_.DROP_P, int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
+def _scores_blocks(d: int, t: int):
+    """(task blocks of <= 4, column blocks of <= 512) the pool kernels' covering instantiation takes (csrc/gated_pool.hip: shape_ok)."""
+    return [(t0, min(t0 + 4, t)) for t0 in range(0, t, 4)], [(d0, min(d0 + 512, d)) for d0 in range(0, d, 512)]
+
+
 class _ScoresFn(torch.autograd.Function):
-    """Standalone Attn_Net_Gated: A = (tanh(xWa^T+ba) * sigmoid(xWb^T+bb)) Wc^T + bc."""
+    """Standalone Attn_Net_Gated: A = (tanh(xWa^T+ba) * sigmoid(xWb^T+bb)) Wc^T + bc, for ANY (L, D, n_tasks) the reference's constructor takes
+    (models/model_toad.py:19). Within the kernels' envelope (L % 8 == 0, D <= 512 with D % 4 == 0, n_tasks <= 4: every shape TOAD itself builds)
+    it is one GEMM + one scores launch. Outside it the same kernels run over blocks: the scores are linear in the gate columns and independent
+    per task, so D is cut into column blocks of <= 512 (summed), n_tasks into blocks of <= 4 (concatenated); a D that is not a multiple of 4 /
+    an L that is not a multiple of 8 is zero-padded (a zero weight row gives tanh(0) * sigmoid(0) = 0: exact)."""
 
     @staticmethod
     def forward(ctx, x, wa, ba, wb, bb, wc, bc, drop_p, seed):
-        wab, bab = torch.cat([wa, wb], 0), torch.cat([ba, bb], 0)
-        p = ops.linear_act_fwd(x, wab, bab, ops.ACT_NONE)
+        d, l = wa.shape
+        t = wc.shape[0]
+        dp_, lp_ = (d + 3) // 4 * 4, (l + 7) // 8 * 8
+        if dp_ != d or lp_ != l:                                   # zero padding (rare shapes): extra weight rows / input columns that contribute nothing
+            pad_w = lambda w: torch.nn.functional.pad(w, (0, lp_ - l, 0, dp_ - d))     # noqa: E731
+            wa_, wb_ = pad_w(wa), pad_w(wb)
+            ba_, bb_ = torch.nn.functional.pad(ba, (0, dp_ - d)), torch.nn.functional.pad(bb, (0, dp_ - d))
+            wc_ = torch.nn.functional.pad(wc, (0, dp_ - d))
+            xp = torch.nn.functional.pad(x, (0, lp_ - l)) if lp_ != l else x
+        else:
+            wa_, wb_, ba_, bb_, wc_, xp = wa, wb, ba, bb, wc, x
+        wab, bab = torch.cat([wa_, wb_], 0), torch.cat([ba_, bb_], 0)
+        p = ops.linear_act_fwd(xp.contiguous(), wab, bab, ops.ACT_NONE)
         _, _, sa, sb = F_.drop_seeds(seed)
-        a_raw, _, _ = ops.gated_pool_fwd(p, wa.shape[0], None, wc, bc, drop_p, sa, sb)
-        ctx.save_for_backward(x, p, wab, wc)
+        tb, db = _scores_blocks(dp_, t)
+        if len(tb) == 1 and len(db) == 1:
+            a_raw, _, _ = ops.gated_pool_fwd(p, dp_, None, wc_.contiguous(), bc, drop_p, sa, sb)
+        else:
+            a_raw = torch.empty((x.shape[0], t), dtype=torch.float32, device=x.device)
+            zero_b = torch.zeros(4, dtype=torch.float32, device=x.device)
+            for (t0, t1) in tb:
+                acc = None
+                for j, (d0, d1) in enumerate(db):
+                    blk = ops.gate_scores_block_fwd(p, dp_, d0, wc_[t0:t1, d0:d1].contiguous(), bc[t0:t1].contiguous() if j == 0 else zero_b[:t1 - t0],
+                                                    drop_p, sa + j * F_._GOLDEN & _M64, sb + j * F_._GOLDEN & _M64)     # a mask stream per column block
+                    acc = blk if acc is None else acc.add_(blk)
+                a_raw[:, t0:t1] = acc
+        ctx.save_for_backward(xp, p, wab, wc_)
         ctx.need_dx = x.requires_grad
         ctx.drop = (drop_p, sa, sb)
+        ctx.dims = (d, l, dp_, lp_, t)
         return a_raw
 
     @staticmethod
     def backward(ctx, da):
-        x, p, wab, wc = ctx.saved_tensors
-        d, t = wc.shape[1], wc.shape[0]
-        n, l = x.shape
-        dev = x.device
-        # reuse the pooled backward with softmax weight p == 0 (stats = (0, inf)): dS = dA
-        stats = torch.tensor([[0.0, float("inf")]] * t, device=dev)
-        zeros = torch.zeros((t, l), device=dev)
-        if l > 1024 or l % 8 or d > 512 or d % 4 or t > 4:
-            raise NotImplementedError("Attn_Net_Gated on the HIP kernels: L <= 1024 (multiple of 8), D <= 512 (multiple of 4), n_tasks <= 4")
-        dp, _, dwc, dbc = ops.gated_pool_bwd(p, d, x, wc, torch.zeros((n, t), device=dev), stats, zeros, zeros,
-                                             da.contiguous(), drop_p=ctx.drop[0], seed_a=ctx.drop[1], seed_b=ctx.drop[2])
-        dwab, dbab = ops.linear_wgrad(dp, x)
+        xp, p, wab, wc_ = ctx.saved_tensors
+        d, l, dp_, lp_, t = ctx.dims
+        n = xp.shape[0]
+        drop_p, sa, sb = ctx.drop
+        da = da.contiguous()
+        tb, db = _scores_blocks(dp_, t)
+        dp = torch.empty_like(p)
+        dwc = torch.empty_like(wc_)
+        dbc = torch.empty((t,), dtype=torch.float32, device=p.device)
+        for j, (d0, d1) in enumerate(db):
+            for i, (t0, t1) in enumerate(tb):
+                dpa, dpb, dwc_blk, dbc_blk = ops.gate_scores_block_bwd(p, dp_, d0, wc_[t0:t1, d0:d1].contiguous(), da[:, t0:t1].contiguous(), drop_p,
+                                                                       sa + j * F_._GOLDEN & _M64, sb + j * F_._GOLDEN & _M64)
+                if i == 0:                                         # dP is linear in dA: the task blocks of one column block add up
+                    dp[:, d0:d1], dp[:, dp_ + d0:dp_ + d1] = dpa, dpb
+                else:
+                    dp[:, d0:d1] += dpa; dp[:, dp_ + d0:dp_ + d1] += dpb
+                dwc[t0:t1, d0:d1] = dwc_blk
+                if j == 0:
+                    dbc[t0:t1] = dbc_blk                           # column sums of dA: the same from every column block
+        dwab, dbab = ops.linear_wgrad(dp, xp)
         dx = ops.linear_dgrad(dp, ops.transpose(wab)) if ctx.need_dx else None
-        return dx, dwab[:d], dbab[:d], dwab[d:], dbab[d:], dwc, dbc, None, None
+        if dx is not None and lp_ != l:
+            dx = dx[:, :l].contiguous()
+        return (dx, dwab[:d, :l], dbab[:d], dwab[dp_:dp_ + d, :l], dbab[dp_:dp_ + d], dwc[:, :d], dbc, None, None)
 
 
 class Attn_Net_Gated(nn.Module):

@@ -309,6 +309,48 @@ def gated_pool_bwd(p, d: int, h, wc, a_raw, stats, m, dm, da_ext=None, dwc=None,
     return dp, dh, dwc, dbc
 
 
+# ---- scores only, over a column block of the stacked pre-activations (standalone Attn_Net_Gated of any shape) -------------------------
+# The pool kernels' covering instantiation takes D <= 512 (multiple of 4) and n_tasks <= 4. The scores are linear in the gate columns and
+# independent per task, so any (D, n_tasks) is a sum over column blocks of <= 512 and a concatenation over task blocks of <= 4
+# (toad_amd.model_toad._ScoresFn drives the blocks). ``p`` is the [N, 2*dtot] stacked pre-activation matrix; the block is columns
+# [d0, d0 + wc.shape[1]) of its tanh half and of its sigmoid half.
+def gate_scores_block_fwd(p: torch.Tensor, dtot: int, d0: int, wc: torch.Tensor, bc: torch.Tensor, drop_p: float = 0.0, seed_a: int = 0, seed_b: int = 0):
+    """A_block [N, T_blk] = (tanh(Pa[:, blk]) * sigmoid(Pb[:, blk])) wc^T + bc for one (task block, column block)."""
+    _chk(p, "p"); _chk(wc, "wc"); _chk(bc, "bc")
+    n, ldp = p.shape
+    t, d = wc.shape
+    if ldp != 2 * dtot or d0 % 4 or d % 4 or dtot % 4 or d0 + d > dtot or d > 512 or t > 4 or bc.numel() != t:
+        raise ValueError("gate_scores_block_fwd: bad block")
+    a_raw = torch.empty((n, t), dtype=torch.float32, device=p.device)
+    _lib.check(_lib.load().toad_gated_pool_fwd_f32(p.data_ptr() + 4 * d0, p.data_ptr() + 4 * (dtot + d0), ldp, None, _p(wc), _p(bc), _p(a_raw), None, None,
+                                                   None, 0, n, 8, d, t, float(drop_p), int(seed_a), int(seed_b), _stream()), "toad_gated_pool_fwd_f32")
+    return a_raw
+
+
+def gate_scores_block_bwd(p: torch.Tensor, dtot: int, d0: int, wc: torch.Tensor, da: torch.Tensor, drop_p: float = 0.0, seed_a: int = 0, seed_b: int = 0):
+    """Backward of gate_scores_block_fwd for the external gradient ``da`` [N, T_blk]: returns (dPa_blk [N, d], dPb_blk [N, d], dWc_blk, dbc_blk).
+    The pooled backward is reused with softmax weights of zero (stats = (0, inf)) and a zero pooled gradient: dS = dA exactly; its H operand is
+    then multiplied by zeros only, so an 8-column dummy stands in for it (no limit on the layer's L)."""
+    _chk(p, "p"); _chk(wc, "wc"); _chk(da, "da")
+    n, ldp = p.shape
+    t, d = wc.shape
+    if ldp != 2 * dtot or d0 % 4 or d % 4 or dtot % 4 or d0 + d > dtot or d > 512 or t > 4 or tuple(da.shape) != (n, t):
+        raise ValueError("gate_scores_block_bwd: bad block")
+    dev = p.device
+    lib = _lib.load()
+    h = torch.zeros((n, 8), dtype=torch.float32, device=dev)
+    zeros_tl = torch.zeros((t, 8), dtype=torch.float32, device=dev)
+    a0 = torch.zeros((n, t), dtype=torch.float32, device=dev)
+    stats = torch.tensor([[0.0, float("inf")]] * t, dtype=torch.float32, device=dev)
+    dp = torch.empty((n, 2 * d), dtype=torch.float32, device=dev)
+    dwc = torch.empty_like(wc); dbc = torch.empty((t,), dtype=torch.float32, device=dev)
+    ws = _ws(lib.toad_gated_pool_bwd_ws_bytes(n, 8, d, t), dev, "pool")
+    _lib.check(lib.toad_gated_pool_bwd_f32(p.data_ptr() + 4 * d0, p.data_ptr() + 4 * (dtot + d0), ldp, _p(h), _p(wc), _p(a0), _p(stats), _p(zeros_tl), _p(zeros_tl),
+                                           _p(da), _p(dp), dp.data_ptr() + 4 * d, 2 * d, None, _p(dwc), _p(dbc), 0.0, None, _p(ws), ws.numel(), n, 8, d, t,
+                                           float(drop_p), int(seed_a), int(seed_b), _stream()), "toad_gated_pool_bwd_f32")
+    return dp[:, :d], dp[:, d:], dwc, dbc
+
+
 def heads_fwd(m, sex, wcls, bcls, wsite, bsite):
     """Returns (Mcat [2,L+1], logits [1,C], Y_prob, Y_hat [1,1] int64, site_logits [1,2], site_prob, site_hat)."""
     for t_, nm in ((m, "m"), (sex, "sex"), (wcls, "wcls"), (bcls, "bcls"), (wsite, "wsite"), (bsite, "bsite")):
