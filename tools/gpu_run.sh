@@ -70,6 +70,17 @@ for k, v in agg.items():
     print(f"{k:<70} n={len(v)} FETCH_SIZE {sum(v)/len(v)/1024:.1f} MB raw ({2*sum(v)/len(v)/1024:.1f} MB with the gfx950 wide-read x2)")
 PY
       tail -2 $OUT/ctraffic.log ;;
+    steptraffic)    # HBM bytes of every kernel of the fused step (raw fp32 bag): separate FETCH_SIZE / WRITE_SIZE passes over tools/pmc_step.py
+      for c in FETCH_SIZE WRITE_SIZE; do
+        (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/steptraffic/$c -o p -- python $ROOT/tools/pmc_step.py ${arg:-100000} 3 > $OUT/steptraffic_$c.log 2>&1)
+        find $OUT/steptraffic/$c -name "*.db" -delete
+      done; ls $OUT/steptraffic/* | head ;;
+    mfma)           # what the power cap leaves of the matrix pipe (tools/ubench/mfma_power: arms 0-3, random operands)
+      (cd tools/ubench && [ -x mfma_power ] || hipcc --offload-arch=gfx950 -O3 -o mfma_power mfma_power.hip) ; timeout 120 tools/ubench/mfma_power ${arg:-2} > $OUT/mfma_power.txt 2>&1; cat $OUT/mfma_power.txt ;;
+    hbm)            # streaming rates of read-only / copy / 2R:1W / 3R:1W kernels (tools/ubench/hbm_mix)
+      (cd tools/ubench && [ -x hbm_mix ] || hipcc --offload-arch=gfx950 -O3 -o hbm_mix hbm_mix.hip) ; timeout 120 tools/ubench/hbm_mix > $OUT/hbm_mix.txt 2>&1; cat $OUT/hbm_mix.txt ;;
+    closing)        # the GEMM chain's closing table from this call's ab / mfma / hbm / steptraffic outputs
+      python tools/gemm_closing_table.py $OUT/ab.txt $OUT/mfma_power.txt $OUT/hbm_mix.txt $OUT/steptraffic ${arg:-100000} > $OUT/gemm_closing_table.md 2> $OUT/closing.err; cat $OUT/gemm_closing_table.md; tail -3 $OUT/closing.err ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
     *) echo "unknown job $what" ;;
