@@ -1,0 +1,86 @@
+"""The extractor's closing table (VERDICT r04 item 4 asked for >= 0.35 of the MFMA ceiling by removing bytes): per group of convolutions of one
+toad_resnet50_trunc_fwd_f32 call (B tiles of 256 x 256)
+
+    achieved us            rocprofv3 kernel trace of the call (tools/extractor_bench.py), last of the calls in the trace
+    MFMA-only us           3 x 2MNK fp16-MFMA flops / the power-capped register-only MFMA rate (tools/ubench/mfma_power arm 0, same box)
+    traffic us             ALGORITHMIC bytes of the layer (input once, residual once, output once; fp32 NHWC) / the 2R:1W streaming rate
+                           (tools/ubench/hbm_mix, same box)
+    achieved / (sum)       against the energy-additive floor (the socket is at its power cap: matrix energy and byte energy add)
+
+and, from the same numbers, what each candidate fusion would save. usage:
+    python tools/extractor_closing_table.py <kernel_trace.csv> mfma_power.txt hbm_mix.txt [B] > profiles/r05_extractor_closing_table.md"""
+import csv, re, sys
+
+trace, mfma, hbm = sys.argv[1:4]
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 512
+rows = [r for r in csv.DictReader(open(trace))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+g = [(dur(r), r["Kernel_Name"]) for r in rows if "gemm_nt_h2" in r["Kernel_Name"] or "conv3x3_h2" in r["Kernel_Name"] or "stem_halo_pool" in r["Kernel_Name"]]
+last = g[-43:]
+t0 = int([r for r in rows if "stem_halo_pool" in r["Kernel_Name"]][-1]["Start_Timestamp"])
+call_rows = [r for r in rows if int(r["Start_Timestamp"]) >= t0]
+call_us = (max(int(r["End_Timestamp"]) for r in call_rows) - t0) / 1e3
+other_us = sum(dur(r) for r in call_rows) - sum(u for u, _ in last)
+m = re.search(r"arm 0[^:]*:\s*[\d.]+ ms,\s*([\d.]+) TFLOP/s", open(mfma).read())
+mfma_tf = float(m.group(1))
+h = open(hbm).read()
+mix = float(re.search(r"2 R : 1 W\s+[\d.]+ ms\s+([\d.]+) TB/s", h).group(1))
+# (name, M_out, K, N, input bytes, residual bytes, output bytes)
+order = [("stem+pool", B * 128 * 128, 147, 64, B * 3 * 256 * 256 * 4, 0, B * 64 * 64 * 64 * 4)]
+inpl, hh = 64, 64
+for li, (pl, blocks, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2)), 1):
+    for b in range(blocks):
+        s = stride if b == 0 else 1
+        ho = (hh + 2 - 3) // s + 1
+        Mi, Mo = B * hh * hh, B * ho * ho
+        order.append((f"layer{li} conv1 1x1 {inpl}->{pl}", Mi, inpl, pl, Mi * inpl * 4, 0, Mi * pl * 4))
+        order.append((f"layer{li} conv2 3x3/{s} {pl}->{pl}", Mo, 9 * pl, pl, Mi * pl * 4, 0, Mo * pl * 4))
+        if b == 0:
+            order.append((f"layer{li} downsample 1x1/{s} {inpl}->{4 * pl}", Mo, inpl, 4 * pl, (Mo if s == 1 else Mi) * inpl * 4, 0, Mo * 4 * pl * 4))
+        order.append((f"layer{li} conv3 1x1 {pl}->{4 * pl} + residual", Mo, pl, 4 * pl, Mo * pl * 4, Mo * 4 * pl * 4, Mo * 4 * pl * 4))
+        inpl, hh = 4 * pl, ho
+agg = {}
+for (name, M, K, N, bi, br, bo), (us, kn) in zip(order, last):
+    a = agg.setdefault(name, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += us; a[2] += 2.0 * M * K * N; a[3] += bi + br + bo
+print(f"# r05: closing table of the feature extractor, one toad_resnet50_trunc_fwd_f32 call on {B} tiles of 256 x 256 (same box and gpurun call for every column)\n")
+print(f"* achieved: rocprofv3 --kernel-trace of `tools/extractor_bench.py {B}`, last call in the trace: {call_us:.0f} us from the stem's start to the last kernel's end "
+      f"({B / call_us * 1e6:.0f} patches/s); 43 convolution launches {sum(u for u, _ in last):.0f} us, everything else (gathers, average pool, memsets) {other_us:.0f} us")
+print(f"* MFMA-only: `mfma_power` arm 0 = {mfma_tf:.0f} TFLOP/s of fp16 MFMA at the power cap = {mfma_tf / 3:.0f} TF fp32-equivalent; traffic: algorithmic bytes (fp32 NHWC: input once, "
+      f"residual once, output once) at `hbm_mix`'s 2R:1W rate, {mix:.2f} TB/s\n")
+print("| layers | n | us (sum) | GFLOP-eq | TF-eq | MFMA-only us | algorithmic GB | traffic us | MFMA-only + traffic | achieved / (sum) |")
+print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
+T = [0.0, 0.0, 0.0, 0.0]
+for name, (c, us, fl, by) in agg.items():
+    tm, tt = 3 * fl / (mfma_tf * 1e12) * 1e6, by / (mix * 1e12) * 1e6
+    print(f"| {name} | {c} | {us:.0f} | {fl / 1e9:.0f} | {fl / us / 1e6:.0f} | {tm:.0f} | {by / 1e9:.2f} | {tt:.0f} | {tm + tt:.0f} | {us / (tm + tt):.2f} |")
+    T[0] += us; T[1] += fl; T[2] += tm; T[3] += by
+tt = T[3] / (mix * 1e12) * 1e6
+print(f"| **all 43 convolutions** | 43 | **{T[0]:.0f}** | {T[1] / 1e9:.0f} | {T[1] / T[0] / 1e6:.0f} | {T[2]:.0f} | {T[3] / 1e9:.1f} | {tt:.0f} | {T[2] + tt:.0f} | **{T[0] / (T[2] + tt):.2f}** |")
+print(f"\nFraction of the nominal 833.3 TF: {T[1] / (call_us * 1e-6) / 1e12 / 833.3:.3f} (whole call). MFMA-only {T[2] / 1e3:.1f} ms + traffic {tt / 1e3:.1f} ms = "
+      f"{(T[2] + tt) / 1e3:.1f} ms against {T[0] / 1e3:.1f} ms achieved by the convolutions: the call sits on the energy-additive floor of its own algorithm "
+      f"(fp32 NHWC activations between all 43 convolutions, three MFMA terms per product).\n")
+# ---- what the candidate fusions would buy, priced with the same two rates
+print("## Candidate fusions, priced with the same rates (bytes removed - bytes added by halo re-reads; matrix work added by halo recompute)\n")
+print("| fusion | blocks | bytes removed GB | halo bytes added GB | net GB | extra matrix us | net us saved (additive model) | of the call |")
+print("|---|---:|---:|---:|---:|---:|---:|---:|")
+tot_saved = 0.0
+for li, (pl, blocks, hh_, inpl_first) in enumerate(((64, 3, 64, 64), (128, 4, 32, 256)), 1):
+    # conv1 -> conv2 with the mid tile in LDS: removes the mid tensor's write and its (1.3x, halo) read; the block input is then read with a halo
+    # (18 x 18 for a 16 x 16 output tile = 1.27x), and conv1 is recomputed on the halo (1.27x its flops). Stride-1 blocks only (b >= 1; layer1 b = 0 too).
+    for b in range(blocks):
+        s = 2 if (b == 0 and li > 1) else 1
+        if s != 1:
+            continue
+        Mi = B * hh_ * hh_
+        cin = inpl_first if b == 0 else 4 * pl
+        mid = Mi * pl * 4
+        removed, added = mid * (1.0 + 1.3), 0.27 * Mi * cin * 4
+        extra_us = 0.27 * 3 * 2.0 * Mi * cin * pl / (mfma_tf * 1e12) * 1e6
+        saved = (removed - added) / (mix * 1e12) * 1e6 - extra_us
+        tot_saved += saved
+        print(f"| layer{li}.{b} conv1 -> conv2 (mid tile in LDS, 16 x 16 output tiles) | 1 | {removed / 1e9:.2f} | {added / 1e9:.2f} | {(removed - added) / 1e9:.2f} | {extra_us:.0f} | {saved:.0f} | {saved / call_us * 100:.1f} % |")
+print(f"| **all stride-1 blocks of layer1 / layer2** | | | | | | **{tot_saved:.0f}** | **{tot_saved / call_us * 100:.1f} %** |")
+print("\nThe mid tensors are the NARROW ones (64 / 128 channels); the block inputs the fused kernel would have to re-read with a halo are the WIDE ones "
+      "(256 / 512 channels), so most of what the fusion removes it adds back. Under the additive model the review's fusion is worth the last line - not the "
+      "15-20 % a byte count of the mid tensor alone suggests - and it was not built.")

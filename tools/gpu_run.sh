@@ -81,6 +81,8 @@ PY
       (cd tools/ubench && [ -x hbm_mix ] || hipcc --offload-arch=gfx950 -O3 -o hbm_mix hbm_mix.hip) ; timeout 120 tools/ubench/hbm_mix > $OUT/hbm_mix.txt 2>&1; cat $OUT/hbm_mix.txt ;;
     closing)        # the GEMM chain's closing table from this call's ab / mfma / hbm / steptraffic outputs
       python tools/gemm_closing_table.py $OUT/ab.txt $OUT/mfma_power.txt $OUT/hbm_mix.txt $OUT/steptraffic ${arg:-100000} > $OUT/gemm_closing_table.md 2> $OUT/closing.err; cat $OUT/gemm_closing_table.md; tail -3 $OUT/closing.err ;;
+    xclosing)       # the extractor's closing table from this call's xstats trace + mfma / hbm outputs
+      python tools/extractor_closing_table.py $(find $OUT/xprof -name "*kernel_trace.csv" | head -1) $OUT/mfma_power.txt $OUT/hbm_mix.txt ${arg:-512} > $OUT/extractor_closing_table.md 2> $OUT/xclosing.err; cat $OUT/extractor_closing_table.md; tail -3 $OUT/xclosing.err ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
     *) echo "unknown job $what" ;;
