@@ -69,7 +69,20 @@ def cpu_extractor_baseline(n_tiles: int = 8, budget_s: float = 25.0):
                       + ", ".join(f"{k}: {v * 1e3:.0f} ms" for k, v in probe.items()) + "}"}
 
 
-TRAFFIC_FILE = "r04_extractor_traffic.json"      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one extractor call (tools/gpu_run.sh xtraffic)
+TRAFFIC_FILE = "r05_extractor_traffic.json"      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one extractor call (tools/gpu_run.sh xtraffic)
+EXTRACTOR_KERNEL_SOURCES = ("toad_amd/csrc/conv.hip", "toad_amd/csrc/gemm_f32.hip", "toad_amd/csrc/gemm_h2.inc", "toad_amd/csrc/gemm_h2_epilogue.inc",
+                            "toad_amd/csrc/gemm_narrow.inc", "toad_amd/csrc/gemm_stream.inc", "toad_amd/csrc/stem_halo.inc", "toad_amd/csrc/common.h")
+
+
+def extractor_kernel_sha() -> str:
+    """sha256 over the sources the extractor's kernels are compiled from: ties the committed traffic measurement to a kernel build (as bench.py does
+    for the pool kernels); a later edit to any of them makes `roofline.traffic` null instead of silently stale."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in EXTRACTOR_KERNEL_SOURCES:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def extractor_traffic(chunk, n, ext_ms):
@@ -81,6 +94,8 @@ def extractor_traffic(chunk, n, ext_ms):
         return None, "no PMC file for this round"
     if t.get("tiles_per_call") != chunk:
         return None, f"profiles/{TRAFFIC_FILE} was measured at {t.get('tiles_per_call')} tiles per call"
+    if t.get("kernel_source_sha256") != extractor_kernel_sha():
+        return None, f"profiles/{TRAFFIC_FILE} was measured on other kernel sources (sha mismatch): re-run tools/gpu_run.sh TAG xtraffic"
     per_call = t["hbm_bytes_per_call"]["total_with_fetch_x2"]
     tbs = per_call * (n / chunk) / (ext_ms * 1e-3) / 1e12
     return per_call, (f"HBM bytes per extractor call of {chunk} tiles (profiles/{TRAFFIC_FILE}: FETCH_SIZE x2 + WRITE_SIZE, separate passes); algorithmic "

@@ -147,6 +147,44 @@ static DropSeeds drop_seeds(float drop_p, uint64_t seed) {          // must matc
 
 #define TOAD_TRY(call) do { const int rc_ = (call); if (rc_) return rc_; } while (0)
 
+// ---- bags beyond the NT kernels' 32-bit row offsets (more than ~1.05 M patches): the same kernels over ROW CHUNKS -----------------------------
+// gemm_nt_h2_big_kernel addresses its A operand with 32-bit byte offsets (h2_nt_ok: M * lda * 4 < 2^32, i.e. 1,048,575 rows of the 1024-wide
+// bag). Rows of an NT product are independent, so a longer bag runs as consecutive launches over chunks of kChunkRows rows (a multiple of the
+// 256-row blocks the abs-max arrays, the one-bit ReLU images and the per-tile scales are indexed by): every per-row pointer advances by the
+// chunk's first row, the weight planes are shared. Until round 5 such bags fell back to the exact-fp32 128 x 128 kernels (5x slower).
+// A chunk of at most kChunkRows rows is ONE launch with exactly the arguments of the unchunked call, so nothing changes for ordinary bags.
+// Train-mode dropout in the epilogue hashes the element index INSIDE a launch: chunk j > 0 therefore draws its masks from the stream
+// seed + j * kChunkSeedStep at the chunk-local index (toad_dropout_mask_f32 reproduces them chunk by chunk); the backward never recomputes
+// trunk masks (the saved outputs carry them), so the two passes cannot disagree. The weight gradients reduce over rows inside ONE launch of the
+// TN kernels, which take any M.
+constexpr int64_t kChunkRows = 4092 * 256;                  // 1,047,552 rows: 4,290,772,992 bytes of a 1024-wide fp32 operand
+constexpr uint64_t kChunkSeedStep = 0xD1B54A32D192ED03ull;
+static bool nt_rows_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc) {
+    return h2_nt_ok(M < kChunkRows ? M : kChunkRows, N, K, lda, ldc);
+}
+static int nt_rows(const float *A, int64_t lda, const float *a_amax, const unsigned short *planes, const float *binv, float *C, int64_t ldc, int64_t M,
+                   int64_t N, int64_t K, const float *bias, EpiScalars es, const float *addend, const float *mask_src,
+                   const unsigned long long *mask_bits, H2Pool pool, float *slabs, float *y_amax, unsigned long long *bits_out, hipStream_t st,
+                   const char *what, int a_mode = TOAD_X_F32, float *a_amax_out = nullptr, int *slab_ke = nullptr) {
+    if (M <= kChunkRows)
+        return launch_nt_h2(A, lda, a_amax, planes, binv, C, ldc, M, N, K, bias, es, addend, mask_src, mask_bits, pool, slabs, y_amax, bits_out, st, what,
+                            a_mode, 1, 1, a_amax_out, slab_ke);
+    if (a_mode != TOAD_X_F32) { set_error("%s: an fp16 / prepared bag is limited to the kernels' 32-bit row offsets", what); return TOAD_ESHAPE; }
+    const int64_t bits_per_blk = (int64_t)((N + 255) / 256) * 8 * 2 * 64;          // 64-bit words of the ReLU image per 256-row block (toad_relu_bits_bytes)
+    int j = 0;
+    for (int64_t c0 = 0; c0 < M; c0 += kChunkRows, ++j) {
+        const int64_t m = M - c0 < kChunkRows ? M - c0 : kChunkRows, blk = c0 / H2_ROWBLK;
+        EpiScalars e = es;
+        if (e.drop.thresh) e.drop.seed += (uint64_t)j * kChunkSeedStep;
+        H2Pool pl = pool;
+        if (pl.T > 0) pl.a_raw += c0 * pl.T;
+        TOAD_TRY(launch_nt_h2(A + c0 * lda, lda, a_amax ? a_amax + blk : nullptr, planes, binv, C + c0 * ldc, ldc, m, N, K, bias, e, addend ? addend + c0 * ldc : nullptr,
+                              mask_src ? mask_src + c0 * ldc : nullptr, mask_bits ? mask_bits + blk * bits_per_blk : nullptr, pl, slabs, y_amax ? y_amax + blk : nullptr,
+                              bits_out ? bits_out + blk * bits_per_blk : nullptr, st, what, a_mode, 1, 1, a_amax_out ? a_amax_out + blk : nullptr, slab_ke));
+    }
+    return TOAD_OK;
+}
+
 // forward up to the pooled features: trunk, stacked attention GEMM, fused gated pool. `ev` records bench events (or nothing).
 template <typename Ev>
 static int forward_body(const MilShape &s, const Params &p, const float *X, const float *x_amax, float drop_p, uint64_t seed,
@@ -155,7 +193,7 @@ static int forward_body(const MilShape &s, const Params &p, const float *X, cons
     const int64_t N = s.N;
     const int D2 = 2 * s.D;
     const DropSeeds ds = drop_seeds(drop_p, seed);
-    const bool h2 = h2_nt_ok(N, kL, kL0, kL0, kL);
+    const bool h2 = x_mode == TOAD_X_F32 ? nt_rows_ok(N, kL, kL0, kL0, kL) : h2_nt_ok(N, kL, kL0, kL0, kL);     // fp32 bags of any length: row chunks (nt_rows)
     if (x_mode != TOAD_X_F32 && !h2) { set_error("%s: an fp16 / prepared bag needs the fp16 two-piece kernels (N * 1024 * 4 < 2^32)", what); return TOAD_ESHAPE; }
     if (x_mode == TOAD_X_PT && !x_amax) { set_error("%s: a prepared bag comes with its abs-max array", what); return TOAD_EINVAL; }
     const EpiScalars relu1{1, 1.f, make_drop(drop_p, ds.s1)}, relu2{1, 1.f, make_drop(drop_p, ds.s2)}, lin{0, 1.f, make_drop(0.f, 0)};
@@ -180,14 +218,14 @@ static int forward_body(const MilShape &s, const Params &p, const float *X, cons
         const float *ax = x_mode == TOAD_X_PT ? x_amax : f.amax_x;    // a prepared bag carries its own array: nothing to copy or measure
         // a raw fp32 bag without an abs-max array is measured INSIDE the first GEMM (running block maximum, gemm_h2.inc AMODE 3), which fills
         // f.amax_x (zeroed by the split launch above) for the weight gradient of this layer: no pass over the bag of its own
-        const bool self_measure = x_mode == TOAD_X_F32 && !x_amax && nt_run_ok(N, kL, kL0);
+        const bool self_measure = x_mode == TOAD_X_F32 && !x_amax && nt_run_ok(N < kChunkRows ? N : kChunkRows, kL, kL0);
         if (x_mode == TOAD_X_F32 && !x_amax && !self_measure) TOAD_TRY(launch_absmax(X, kL0, N, kL0, f.amax_x, false, st, what));
         if (x_mode == TOAD_X_F32 && x_amax) (void)hipMemcpyAsync(f.amax_x, x_amax, toad_amax_floats(N) * sizeof(float), hipMemcpyDeviceToDevice, st);
-        ev(2); TOAD_TRY(launch_nt_h2(X, kL0, self_measure ? nullptr : ax, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool,
-                                     w.slabs, f.amax_h1, f.bits_h1, st, what, x_mode, 1, 1, self_measure ? f.amax_x : nullptr, self_measure ? w.slab_ke : nullptr)); ev(3);
-        ev(4); TOAD_TRY(launch_nt_h2(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h, f.bits_h, st, what)); ev(5);
-        ev(6); TOAD_TRY(launch_nt_h2(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nullptr, nopool, w.slabs, nullptr, nullptr, st, what)); ev(7);
-    } else {       // shapes beyond the persistent kernels' 32-bit offsets (> 1 M patches): the per-op entry points pick their kernels
+        ev(2); TOAD_TRY(nt_rows(X, kL0, self_measure ? nullptr : ax, w.planes[W_1], w.binv[W_1], f.H1, kL, N, kL, kL0, p.b1, relu1, nullptr, nullptr, nullptr, nopool,
+                                w.slabs, f.amax_h1, f.bits_h1, st, what, x_mode, self_measure ? f.amax_x : nullptr, self_measure ? w.slab_ke : nullptr)); ev(3);
+        ev(4); TOAD_TRY(nt_rows(f.H1, kL, f.amax_h1, w.planes[W_2], w.binv[W_2], f.H, kL, N, kL, kL, p.b2, relu2, nullptr, nullptr, nullptr, nopool, w.slabs, f.amax_h, f.bits_h, st, what)); ev(5);
+        ev(6); TOAD_TRY(nt_rows(f.H, kL, f.amax_h, w.planes[W_AB], w.binv[W_AB], f.P, D2, N, D2, kL, p.bab, lin, nullptr, nullptr, nullptr, nopool, w.slabs, nullptr, nullptr, st, what)); ev(7);
+    } else {       // (unreachable for the TOAD shapes since round 5; kept for operands the NT kernels refuse for another reason)
         ev(2); TOAD_TRY(toad_linear_act_fwd_f32(X, p.w1, p.b1, f.H1, N, kL0, kL, TOAD_ACT_RELU, drop_p, ds.s1, nullptr, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(3);
         ev(4); TOAD_TRY(toad_linear_act_fwd_f32(f.H1, p.w2, p.b2, f.H, N, kL, kL, TOAD_ACT_RELU, drop_p, ds.s2, nullptr, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(5);
         ev(6); TOAD_TRY(toad_linear_act_fwd_f32(f.H, p.wab, p.bab, f.P, N, kL, D2, TOAD_ACT_NONE, 0.f, 0, nullptr, nullptr, nullptr, w.gemm_ws, w.gemm_ws_bytes, st)); ev(7);
@@ -208,7 +246,7 @@ static int backward_body(const MilShape &s, const Params &p, float *const *grads
     const int64_t N = s.N;
     const int D2 = 2 * s.D;
     const DropSeeds ds = drop_seeds(drop_p, seed);
-    const bool h2 = h2_nt_ok(N, kL, kL0, kL0, kL);
+    const bool h2 = x_mode == TOAD_X_F32 ? nt_rows_ok(N, kL, kL0, kL0, kL) : h2_nt_ok(N, kL, kL0, kL0, kL);
     if (x_mode != TOAD_X_F32 && !h2) { set_error("%s: an fp16 / prepared bag needs the fp16 two-piece kernels", what); return TOAD_ESHAPE; }
     const EpiScalars msk{0, ds.mscale, make_drop(0.f, 0)}, plain{0, 1.f, make_drop(0.f, 0)};
     const H2Pool nopool{nullptr, nullptr, nullptr, 0};
@@ -225,15 +263,15 @@ static int backward_body(const MilShape &s, const Params &p, float *const *grads
         WgradDeferred dw[3];
         ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what, TOAD_X_F32, &dw[0])); ev(9);
         // dZ2 = (dP Wab + dH_pool) * (H > 0): the pooling gradient dH_pool is recomputed in the epilogue from A_raw, stats, dM
-        ev(10); TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, nullptr, f.H, f.bits_h,
-                                      H2Pool{f.A_raw, f.stats, dM, kT}, w.slabs, w.amax_dZ2, nullptr, st, what)); ev(11);
+        ev(10); TOAD_TRY(nt_rows(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, nullptr, f.H, f.bits_h,
+                                 H2Pool{f.A_raw, f.stats, dM, kT}, w.slabs, w.amax_dZ2, nullptr, st, what)); ev(11);
         ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws2, st, what, TOAD_X_F32, &dw[1])); ev(13);
-        ev(14); TOAD_TRY(launch_nt_h2(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, f.bits_h1, nopool,
-                                      w.slabs, w.amax_dZ1, nullptr, st, what)); ev(15);
+        ev(14); TOAD_TRY(nt_rows(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, f.bits_h1, nopool,
+                                 w.slabs, w.amax_dZ1, nullptr, st, what)); ev(15);
         ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, X, x_mode == TOAD_X_PT ? x_amax_pt : f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws3, st, what, x_mode, &dw[2]));
         TOAD_TRY(launch_wgrad_reduce(dw, 3, st, what)); ev(17);
-        if (dX) TOAD_TRY(launch_nt_h2(w.dZ1, kL, w.amax_dZ1, w.planes[W_1T], w.binv[W_1T], dX, kL0, N, kL0, kL, nullptr, plain, nullptr, nullptr, nullptr, nopool,
-                                      w.slabs, nullptr, nullptr, st, what));
+        if (dX) TOAD_TRY(nt_rows(w.dZ1, kL, w.amax_dZ1, w.planes[W_1T], w.binv[W_1T], dX, kL0, N, kL0, kL, nullptr, plain, nullptr, nullptr, nullptr, nopool,
+                                 w.slabs, nullptr, nullptr, st, what));
         return TOAD_OK;
     }
     // legacy sequence (per-op entry points, materialised dH_pool in the dZ2 buffer, explicit transposes)
@@ -390,7 +428,7 @@ static int mil_step_impl(const float *const *params, float *const *grads, float 
     const Scratch w = scratch_layout(s, sb);
     hipStream_t st = (hipStream_t)stream;
     const StreamEvents ev{events, st};
-    const bool presplit = h2_nt_ok(N, kL, kL0, kL0, kL);
+    const bool presplit = x_mode == TOAD_X_F32 ? nt_rows_ok(N, kL, kL0, kL0, kL) : h2_nt_ok(N, kL, kL0, kL0, kL);
     TOAD_TRY(forward_body(s, p, X, x_amax, drop_p, seed, false, f, w, st, ev, what, x_mode, presplit));
     // heads + weighted CE + heads backward: one single-workgroup launch
     TOAD_TRY(toad_heads_ce_fused_f32(f.M, sex, p.wcls, p.bcls, p.wsite, p.bsite, label, site, w_cls, w_site, f.Mcat, f.logits, f.yprob, f.yhat,

@@ -3,7 +3,9 @@
 FETCH_SIZE is doubled for kernels whose reads are wide coalesced streams (gfx950 tallies a 128-byte request at half its bytes: MI355X_MICROARCH.md, HBM /
 rocprofv3 section); the raw figures are kept beside the corrected ones.
 usage: python tools/extractor_traffic_json.py <dir with FETCH_SIZE/ and WRITE_SIZE/> <B> <calls in the trace>"""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench_extract import EXTRACTOR_KERNEL_SOURCES, extractor_kernel_sha
 out_dir, B, calls = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -41,7 +43,7 @@ def algorithmic(B):
             inpl, hh = 4 * pl, ho
     t += B * 16 * 16 * 1024 * 4 + B * 1024 * 4               # average pool
     return t
-print(json.dumps({"tiles_per_call": B, "calls_in_trace": calls,
+print(json.dumps({"tiles_per_call": B, "calls_in_trace": calls, "kernel_source_sha256": extractor_kernel_sha(), "kernel_sources": list(EXTRACTOR_KERNEL_SOURCES),
                   "hbm_bytes_per_call": {"fetch_raw": fetch, "fetch_x2": 2 * fetch, "write": write, "total_with_fetch_x2": 2 * fetch + write},
                   "algorithmic_bytes_per_call": algorithmic(B),
                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) on tools/extractor_bench.py; KB units; "
