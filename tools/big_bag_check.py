@@ -26,3 +26,15 @@ print("logits diff", (out_b["logits"] - out_s["logits"]).abs().max().item(), "A 
 for k, p in m.named_parameters():
     e = (gb[k] - p.grad).abs().max().item(); s = p.grad.abs().max().item()
     print(f"{k:45s} grad diff {e:.2e} scale {s:.2e}")
+# ---- warm timing of the fused step on the 1.1 M-row bag (round 5: the NT GEMMs run the fp16 two-piece kernels over row chunks, csrc/step.hip nt_rows)
+from toad_amd.dp import SlideShardedDP
+dp = SlideShardedDP(m, {"lr": 1e-4, "weight_decay": 1e-5})
+slide = (big, sex, torch.tensor([3], device=dev), torch.tensor([1], device=dev))
+for _ in range(2):
+    dp.step([slide], 1)
+torch.cuda.synchronize(); t0 = time.time()
+for _ in range(5):
+    dp.step([slide], 1)
+torch.cuda.synchronize()
+ms = (time.time() - t0) / 5 * 1e3
+print(f"fused step on {big.shape[0]} patches: {ms:.2f} ms = {ms / big.shape[0] * 1e5:.3f} ms per 100k patches ({6029312.0 * big.shape[0] / ms / 1e9:.0f} TF-eq whole step)")
