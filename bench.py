@@ -441,7 +441,7 @@ def main():
     ap.add_argument("--no-prepared-legs", action="store_true", help="headline run without the prepared_pipelined / prepared_resident legs")
     ap.add_argument("--patches", type=int, default=0, help="patches per slide (default: 100,000; config 3: 10,000; config 4: 50,000)")
     ap.add_argument("--slides-per-rank", type=int, default=0,
-                    help="slides per rank per optimiser step (default 1; config 3: 13 = the most 10k-patch slides one ragged call of <= 131,072 rows takes). Several small fp32 slides of a rank go through ONE "
+                    help="slides per rank per optimiser step (default 1; config 3: 13 = 130k rows, 3.97 rounds of 256 x 256 tiles). Several small fp32 slides of a rank go through ONE "
                          "ragged multi-slide call (toad_mil_multi_step_f32: the GEMMs run once over the concatenated bags)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE.json config (0 = the headline step; 5 = bench_extract.py)")
     ap.add_argument("--sustain-seconds", type=float, default=8.0, help="length of the sustained leg after the timed region (0 = skip)")
@@ -649,7 +649,7 @@ def main():
                        "arithmetic": "fp32 storage/accumulation; GEMM operands as two fp16 pieces (x*s = h+m, power-of-two scales), 3 MFMA terms = "
                                      "fp32-equivalent, verified vs fp64 (tools/split_emulation.py, tests/test_gpu_h2.py)",
                        "patches_per_slide": n, "slides_per_step": global_slides,
-                       "batching": ("consecutive slides of a rank share ragged multi-slide calls of at most 131,072 rows (toad_mil_multi_step_f32: trunk / "
+                       "batching": ("consecutive slides of a rank share ragged multi-slide calls of at most %d rows (" % SlideShardedDP.BATCH_ROWS + "toad_mil_multi_step_f32: trunk / "
                                     "attention GEMMs once over the concatenated bags, pooling + heads + loss per slide; bags that are not already "
                                     "adjacent in memory are concatenated inside the timed step)"
                                     if batched else "one library call per slide"),

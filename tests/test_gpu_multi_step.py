@@ -122,7 +122,9 @@ def _step_workspace_activations(n, nb, c, d, dev):
 #   (c) the attention dgrad on the one-bit ReLU image with a materialised addend (gemm_nt_h2_big_kernel<true, false, 2, 0>).
 # Reference semantics: utils/core_utils_mtl_concat.py:200-234, one forward / loss / backward per slide; the batch gradient is their sum.
 BIG_BATCHES = [("config4_pair", [50000, 50000], 0.0), ("batch_rows_limit", [65536, 65536], 0.0), ("off_grid_boundaries", [50000, 30001, 20000], 0.0),
-               ("dropout_70k_rows", [40000, 30001], 0.25)]
+               ("dropout_70k_rows", [40000, 30001], 0.25),
+               # round 5 raised the default call size to 524,288 rows (toad_amd/dp.py BATCH_ROWS: ten 50k-patch slides per call): one batch of exactly that size
+               ("default_call_size_524288_rows", [100000, 50000, 50000, 100000, 100000, 100000, 24288], 0.0)]
 
 
 @pytest.mark.parametrize("name,lens,drop_p", BIG_BATCHES, ids=[b[0] for b in BIG_BATCHES])

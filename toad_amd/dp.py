@@ -90,10 +90,11 @@ def hip_batch_grad(model, grads: Dict[str, torch.Tensor], slides: Sequence[Slide
 class SlideShardedDP:
     def __init__(self, model, optimizer_factory: Callable[[Sequence[torch.nn.Parameter]], torch.optim.Optimizer],
                  process_group=None, slide_grad_fn: Optional[Callable] = None, broadcast_from: int = 0,
-                 always_reduce: bool = False, batch_max_patches: Optional[int] = None):
+                 always_reduce: bool = False, batch_max_patches: Optional[int] = None, batch_rows: Optional[int] = None):
         """``batch_max_patches``: slides of at most this many patches are batched into one ragged multi-slide call (default
         ``BATCH_MAX_PATCHES``; 0 = never: every slide takes the per-slide call, whose train-mode dropout masks and operand scales are
-        those of the slide alone).
+        those of the slide alone). ``batch_rows``: most rows of one such call (default ``BATCH_ROWS``; bags that do not lie back to back in one
+        allocation are concatenated by a copy of that size).
         ``always_reduce``: issue the gradient all-reduce whenever a process group exists, also at world size 1 (a sum over one
         rank: the values do not change, but the RCCL communicator and its kernel run on the launch stream exactly as they do at
         N > 1 - the single-GPU proof of the collective path, tests/test_gpu_nccl_world1.py and bench.py's allreduce_us)."""
@@ -140,6 +141,7 @@ class SlideShardedDP:
             self.optimizer = optimizer_factory([self.flat_param])
         self.slide_grad_fn = slide_grad_fn or hip_slide_grad
         self.batch_max_patches = self.BATCH_MAX_PATCHES if batch_max_patches is None else int(batch_max_patches)
+        self.batch_rows = self.BATCH_ROWS if batch_rows is None else int(batch_rows)
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -152,11 +154,13 @@ class SlideShardedDP:
             raise RuntimeError("SlideShardedDP: the model's flat parameter buffer was replaced after construction "
                                "(model.to()/deepcopy/re-flatten); build a new SlideShardedDP for the moved model")
 
-    # slides of at most this many patches are batched into one ragged multi-slide call, up to BATCH_ROWS rows per call. 65,536 lets PAIRS of
-    # 50,000-patch slides (BASELINE config 4) share their GEMM launches: one 50k-patch bag is 392 tiles on 256 CUs (1.5 rounds: half a round of
-    # idle CUs in each of its five row-parallel GEMMs), two are 782 (3.05 rounds) - measured 1.29 -> 1.17 ms per slide (profiles/r04d).
-    BATCH_MAX_PATCHES = 65536
-    BATCH_ROWS = 131072
+    # slides of at most BATCH_MAX_PATCHES patches are batched into ragged multi-slide calls of up to BATCH_ROWS rows. History: 65,536 / 131,072 let PAIRS
+    # of 50,000-patch slides (BASELINE config 4) share their GEMM launches (one 50k-patch bag is 1.5 rounds of 256 x 256 tiles on 256 CUs, two are 3.05:
+    # 1.29 -> 1.17 ms per slide, profiles/r04d). Round 5 sized the call for 288 GB of HBM instead of for one tile-plan round: ten 50k-patch slides per call
+    # (524,288 rows, ~8 GB of workspace) amortise the per-call helpers (weight split, five K-split fix-ups, slab reduction, heads) and the tile tail over
+    # five times the rows: 935 -> 1,022 slides/s on config 4 (profiles/r05g_config4_batch_rows.txt). Both are constructor arguments.
+    BATCH_MAX_PATCHES = 262144
+    BATCH_ROWS = 524288
 
     def accumulate(self, slides: Sequence[Slide], global_slides: int, overwrite: bool = True, batched: Optional[bool] = None):
         """grads (+)= sum over ``slides`` of d(loss)/d(params) / global_slides. With ``overwrite`` the
@@ -177,7 +181,7 @@ class SlideShardedDP:
             losses, first, i = [], True, 0
             while i < len(slides):
                 j, rows = i, 0
-                while j < len(slides) and small(slides[j]) and rows + slides[j][0].shape[0] <= self.BATCH_ROWS:
+                while j < len(slides) and small(slides[j]) and rows + slides[j][0].shape[0] <= self.batch_rows:
                     rows += slides[j][0].shape[0]; j += 1
                 beta = 0.0 if (overwrite and first) else 1.0
                 if j - i >= 2:
