@@ -38,7 +38,7 @@ utils/core_utils_mtl_concat.py:201-234, so nothing about a bag may be computed o
 
 --config 2   1 GPU, single 100k-patch bag, fused gated-attention pool FORWARD only; value = algorithmic GB/s; the oracle's
              gated_pool_fwd timed on the host cores beside it.
---config 3   1 GPU, full step (fwd + CE + bwd + Adam) on 10,000-patch bags, 13 per optimiser step through the ragged multi-slide call (130k rows);
+--config 3   1 GPU, full step (fwd + CE + bwd + Adam) on 10,000-patch bags, 52 per optimiser step = one full ragged multi-slide call (520k rows);
              roofline (pool forward launches of the batch) + roofline_mfma + cpu_baseline (>= 10 repetitions).
 --config 4   64 slides x 50,000 patches per step, slide i on rank i mod G (shard_round_robin), one gradient all-reduce and one
              Adam step per 64 slides: STRONG scaling over G = --gpus; runs at G = 1 too; roofline + roofline_mfma + cpu_baseline
@@ -441,7 +441,7 @@ def main():
     ap.add_argument("--no-prepared-legs", action="store_true", help="headline run without the prepared_pipelined / prepared_resident legs")
     ap.add_argument("--patches", type=int, default=0, help="patches per slide (default: 100,000; config 3: 10,000; config 4: 50,000)")
     ap.add_argument("--slides-per-rank", type=int, default=0,
-                    help="slides per rank per optimiser step (default 1; config 3: 13 = 130k rows, 3.97 rounds of 256 x 256 tiles). Several small fp32 slides of a rank go through ONE "
+                    help="slides per rank per optimiser step (default 1; config 3: 52 = one full ragged call of dp.BATCH_ROWS = 524,288 rows). Several small fp32 slides of a rank go through ONE "
                          "ragged multi-slide call (toad_mil_multi_step_f32: the GEMMs run once over the concatenated bags)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE.json config (0 = the headline step; 5 = bench_extract.py)")
     ap.add_argument("--sustain-seconds", type=float, default=8.0, help="length of the sustained leg after the timed region (0 = skip)")
@@ -541,7 +541,7 @@ def main():
         scaling = "strong"
     else:
         n = args.patches or (10_000 if args.config == 3 else 100_000)
-        spr = args.slides_per_rank or (13 if args.config == 3 else 1)       # 13 x 10k = 130k rows = 3.97 rounds of 256 x 256 tiles on 256 CUs (8 slides: 2.45 rounds)
+        spr = args.slides_per_rank or (52 if args.config == 3 else 1)       # 52 x 10k = 520k rows: one full ragged call of the default size (dp.BATCH_ROWS)
         if spr > 1 and n <= SlideShardedDP.BATCH_MAX_PATCHES:
             BAG_PREPARED = False                                       # the ragged batch call concatenates raw fp32 bags
         nbags = 2                                                      # alternate two resident bags per slide slot
