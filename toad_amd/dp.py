@@ -158,8 +158,10 @@ class SlideShardedDP:
     # of 50,000-patch slides (BASELINE config 4) share their GEMM launches (one 50k-patch bag is 1.5 rounds of 256 x 256 tiles on 256 CUs, two are 3.05:
     # 1.29 -> 1.17 ms per slide, profiles/r04d). Round 5 sized the call for 288 GB of HBM instead of for one tile-plan round: ten 50k-patch slides per call
     # (524,288 rows, ~8 GB of workspace) amortise the per-call helpers (weight split, five K-split fix-ups, slab reduction, heads) and the tile tail over
-    # five times the rows: 935 -> 1,022 slides/s on config 4 (profiles/r05g_config4_batch_rows.txt). Both are constructor arguments.
-    BATCH_MAX_PATCHES = 262144
+    # five times the rows: 935 -> 1,022 slides/s on config 4 (profiles/r05g_config4_batch_rows.txt). Both are constructor arguments. The per-slide
+    # threshold stays at 65,536: a 100k-patch slide fills the chip on its own and the batched call has to materialise the pooling gradient the
+    # per-slide call recomputes in its dgrad epilogue - five 100k-patch slides per call measured 459 slides/s against 461 one by one (profiles/r05i).
+    BATCH_MAX_PATCHES = 65536
     BATCH_ROWS = 524288
 
     def accumulate(self, slides: Sequence[Slide], global_slides: int, overwrite: bool = True, batched: Optional[bool] = None):
