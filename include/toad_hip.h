@@ -287,8 +287,12 @@ int toad_resnet50_trunc_fwd_f32(const float *tiles_nchw, const float *const *wei
  *
  *   params / grads : 12 device pointers each, slots w1 b1 w2 b2 wab bab wc bc wcls bcls wsite bsite
  *                    (wab = [Wa;Wb] stacked [2D,512], bab = [ba;bb]); grads = beta*grads + d loss/d param.
- *   D in {256, 384}; X [N,1024] fp32, N >= 1 (an empty bag has no kernels to run: handle it in the host).
- *   drop_p, seed   : train-mode Dropout(drop_p) masks (0 = off), four streams derived from `seed`.
+ *   D in {256, 384}; X [N,1024] fp32, N >= 1 (an empty bag has no kernels to run: handle it in the host). Any N up to 2^31 - 4096: a bag
+ *                    beyond the NT kernels' 32-bit row offsets (N > 1,048,575) runs the same kernels over row chunks of 1,047,552 rows
+ *                    (csrc/step.hip nt_rows); fp16 / prepared bags keep the single-launch limit (toad_mil_x16_ok).
+ *   drop_p, seed   : train-mode Dropout(drop_p) masks (0 = off), four streams derived from `seed`. In a row-chunked call the trunk masks of
+ *                    chunk j > 0 hash the chunk-local element index under seed_stream + j * 0xD1B54A32D192ED03 (toad_dropout_mask_f32
+ *                    reproduces them chunk by chunk); bags of up to 1,047,552 patches are one chunk and unaffected.
  *   x_amax         : abs-max array of X (toad_absmax_rows256_f32) or NULL = measured inside the call - by the first GEMM itself while it
  *                    converts the bag (no extra pass over X, see toad_linear_act_fwd_f32); arena slot 13 then receives the measured array.
  *
