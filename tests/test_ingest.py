@@ -135,3 +135,58 @@ def test_prefetcher_prepares_bags_on_the_copy_stream(cuda):
             assert (u - v).abs().max().item() <= 5e-6 * max(u.abs().max().item(), 1e-30)
     with pytest.raises(ValueError):
         BagPrefetcher(recs, cuda, dtype=torch.float16, prepare=True)
+
+
+def test_landing_arenas_make_consecutive_bags_their_own_concatenation_cpu():
+    """BagPrefetcher(arena_rows=R): consecutive fp32 bags land back to back in shared buffers of R rows (what bench.py --config 4 assumes of an
+    ingest buffer), values and order unchanged; bags of one buffer are recognised as their own concatenation (ops._adjacent_rows: the ragged
+    multi-slide call then takes them without a copy), a bag that does not fit starts a new buffer, an over-long bag gets its own allocation,
+    fp16 files are up-cast on landing."""
+    from toad_amd import ops
+    from toad_amd.ingest import BagPrefetcher
+    lens = [300, 200, 400, 100, 1500, 64, 700]
+    g = torch.Generator().manual_seed(5)
+    bags = [torch.randn(n, 1024, generator=g) for n in lens]
+    bags[3] = bags[3].half()
+    recs = [(b, i % 18, i % 2, float(i % 2)) for i, b in enumerate(bags)]
+    out = list(BagPrefetcher(recs, "cpu", depth=3, workers=2, arena_rows=1000))
+    assert len(out) == len(lens)
+    for i, (bag, label, site, sex) in enumerate(out):
+        assert bag.dtype == torch.float32 and torch.equal(bag, bags[i].float()) and int(label) == i % 18 and int(site) == i % 2
+    store = [o[0].untyped_storage().data_ptr() for o in out]
+    # 300 + 200 + 400 share buffer 0 (100 more would fit, and does); 1500 > 1000 rows gets its own; 64 + 700 share the next buffer
+    assert store[0] == store[1] == store[2] == store[3] and store[4] not in (store[0], store[5]) and store[5] == store[6] != store[0]
+    cat = ops._adjacent_rows([o[0] for o in out[:4]])
+    assert cat is not None and cat.shape == (1000, 1024) and cat.data_ptr() == out[0][0].data_ptr()
+    assert torch.equal(cat, torch.cat([b.float() for b in bags[:4]], 0))
+    assert ops._adjacent_rows([out[2][0], out[4][0]]) is None            # different allocations: the caller falls back to torch.cat
+    with pytest.raises(ValueError):
+        BagPrefetcher(recs, "cpu", dtype=torch.float16, arena_rows=1000)
+
+
+@pytest.mark.gpu
+def test_landed_bags_step_as_one_ragged_call_without_a_copy(cuda):
+    """On the device: bags landed by BagPrefetcher(arena_rows=...) go through SlideShardedDP's ragged multi-slide call as a zero-copy view of their
+    landing buffer and give bitwise the gradient bucket of the same bags held in separate allocations (which the call concatenates by a copy)."""
+    from toad_amd import TOAD_fc_mtl_concat, ops
+    from toad_amd.dp import SlideShardedDP
+    from toad_amd.ingest import BagPrefetcher
+    lens = [700, 64, 1300, 500]
+    g = torch.Generator().manual_seed(9)
+    recs = [(torch.randn(n, 1024, generator=g), (3 * i) % 18, i % 2, float(i % 2)) for i, n in enumerate(lens)]
+    landed = [(b, sx, lb, st) for (b, lb, st, sx) in BagPrefetcher(recs, cuda, depth=3, arena_rows=4096)]
+    torch.cuda.synchronize()
+    view = ops._adjacent_rows([s[0] for s in landed])
+    assert view is not None and view.shape == (sum(lens), 1024) and view.data_ptr() == landed[0][0].data_ptr()
+    for (b, _, _, _), r in zip(landed, recs):
+        assert torch.equal(b.cpu(), r[0])
+    apart = [(b.clone(), sx, lb, st) for (b, sx, lb, st) in landed]
+    assert ops._adjacent_rows([s[0] for s in apart]) is None
+    out = []
+    for slides in (landed, apart):
+        torch.manual_seed(2)
+        model = TOAD_fc_mtl_concat(n_classes=18); model.relocate(); model.train()
+        dp = SlideShardedDP(model, {"lr": 1e-3, "weight_decay": 1e-5})
+        dp.accumulate(slides, len(slides), batched=True)
+        out.append(dp.flat_grad.clone())
+    assert torch.equal(out[0], out[1]) and out[0].abs().max().item() > 0

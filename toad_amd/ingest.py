@@ -38,8 +38,12 @@ class BagPrefetcher:
     """Iterate ``(bag, label, site, sex)`` device tensors in record order with ``depth`` bags in flight."""
 
     def __init__(self, records: Sequence[Record], device: Union[str, torch.device], depth: int = 2, workers: int = 2,
-                 dtype: Optional[torch.dtype] = torch.float32, prepare: bool = False):
-        """``prepare``: hand the consumer ``ops.PreparedBag`` objects instead of fp32 tensors (toad_bag_prepare_f32, ABI 9): right behind
+                 dtype: Optional[torch.dtype] = torch.float32, prepare: bool = False, arena_rows: int = 0):
+        """``arena_rows`` > 0: consecutive fp32 bags are landed BACK TO BACK in device buffers of that many rows (a new buffer when the next bag
+        does not fit; a bag longer than the buffer gets an allocation of its own) and handed out as views. Bags that share a buffer are their own
+        concatenation, so ``SlideShardedDP`` / ``ops.mil_multi_step`` batch them into one ragged multi-slide call without copying a row
+        (``ops._adjacent_rows``); set it to the DP wrapper's ``batch_rows``. A buffer is released when the last view of it dies.
+        ``prepare``: hand the consumer ``ops.PreparedBag`` objects instead of fp32 tensors (toad_bag_prepare_f32, ABI 9): right behind
         its host-to-device copy, on the COPY stream, every bag is brought into the plane-tiled two-piece form the first Linear and its
         weight gradient take by LDS-DMA, and the fp32 copy is released. The training stream then never measures or splits the bag
         (-3 % of a 100k-patch step, more on boxes where the abs-max pass is slower); bags below 64 patches stay fp32 tensors.
@@ -58,6 +62,24 @@ class BagPrefetcher:
         if self.prepare and not self.on_gpu:
             raise ValueError("BagPrefetcher(prepare=True) needs a HIP device (toad_amd has no CPU path)")
         self.copy_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self.arena_rows = max(0, int(arena_rows))
+        if self.arena_rows and (self.prepare or dtype is not torch.float32):
+            raise ValueError("BagPrefetcher(arena_rows=...) lands fp32 bags: leave dtype at torch.float32 and prepare off")
+        self._arena: Optional[torch.Tensor] = None              # current landing buffer [arena_rows, features] and the rows already taken
+        self._arena_used = 0
+
+    def _land(self, t: torch.Tensor) -> torch.Tensor:
+        """Device fp32 copy of host bag ``t`` inside the current landing buffer (called on the copy stream, in record order)."""
+        n, k = t.shape
+        if n > self.arena_rows or n == 0:
+            return t.to(self.device, non_blocking=True).to(torch.float32)
+        if self._arena is None or self._arena.shape[1] != k or self._arena_used + n > self.arena_rows:
+            self._arena = torch.empty((self.arena_rows, k), dtype=torch.float32, device=self.device)
+            self._arena_used = 0
+        view = self._arena[self._arena_used:self._arena_used + n]
+        view.copy_(t, non_blocking=True)                        # H2D (+ up-cast of fp16 / bf16 files) straight into place
+        self._arena_used += n
+        return view
 
     def __len__(self) -> int:
         return len(self.records)
@@ -78,9 +100,14 @@ class BagPrefetcher:
     def _stage_device(self, host):
         t, meta, sx = host
         if not self.on_gpu:
+            if self.arena_rows:
+                return (self._land(t), meta[0:1], meta[1:2], sx), None
             return (t if self.dtype is None else t.to(self.dtype), meta[0:1], meta[1:2], sx), None
         with torch.cuda.stream(self.copy_stream):
-            bag = t.to(self.device, non_blocking=True)
+            if self.arena_rows:
+                bag = self._land(t)
+            else:
+                bag = t.to(self.device, non_blocking=True)
             if self.dtype is not None and bag.dtype != self.dtype:
                 bag = bag.to(self.dtype)                        # fp16/bf16 on disk: half the PCIe bytes, upcast here
             from . import ops
@@ -115,6 +142,8 @@ class BagPrefetcher:
                 for jx in range(i, min(n, i + self.depth)):
                     if jx not in dev_ready and jx in host_futs and (jx == i or host_futs[jx].done()):
                         dev_ready[jx] = self._stage_device(host_futs.pop(jx).result())   # .result() re-raises loader errors
+                    elif self.arena_rows and jx not in dev_ready:
+                        break                                    # landing buffers are filled in record order: never overtake a bag that is not read yet
                 top_up(i + self.depth + 2)
                 tensors, ev = dev_ready.pop(i)
                 if ev is not None:
