@@ -1,9 +1,10 @@
 #!/bin/bash
-# Board power and shader clock while the fused step runs back to back (rocm-smi sampled every ~0.25 s). usage: power_sample.sh TAG [N]
+# Board power and shader clock while the fused step runs back to back (rocm-smi sampled every ~0.25 s). usage: power_sample.sh TAG [N] [command ...]
+# (a command after N replaces the default load `python tools/ab_step.py N 6000`, e.g. `python tools/extractor_bench.py 512 300`)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; cd $ROOT
 OUT=$ROOT/gpurun_out/${1:-power}; mkdir -p $OUT; N=${2:-100000}
 rocm-smi --showmaxpower --showpower --showclocks 2>&1 | grep -i "power\|sclk\|mclk" > $OUT/idle.txt
-timeout 120 python tools/ab_step.py $N 6000 > $OUT/run.log 2>&1 &
+if [ $# -gt 2 ]; then shift 2; timeout 120 "$@" > $OUT/run.log 2>&1 & else timeout 120 python tools/ab_step.py $N 6000 > $OUT/run.log 2>&1 & fi
 PID=$!
 sleep 6
 for i in $(seq 1 24); do
