@@ -546,6 +546,18 @@ def main():
             BAG_PREPARED = False                                       # the ragged batch call concatenates raw fp32 bags
         nbags = 2                                                      # alternate two resident bags per slide slot
         slides = [[make_slide((rank * spr + s) * nbags + b, n, dev) for s in range(spr)] for b in range(nbags)]
+        if spr > 1 and BAG_DTYPE == torch.float32 and not BAG_PREPARED:
+            # several slides per step: like config 4, the bags of one step lie back to back in ONE resident buffer - the layout the ingest produces
+            # (toad_amd.ingest.BagPrefetcher(arena_rows=dp.batch_rows) lands consecutive slides that way) - so the ragged multi-slide call takes
+            # them as their own concatenation; separately allocated bags would be concatenated by a copy inside every timed step (round 5 measured
+            # that copy at 0.88 ms of 11.4 on 52 x 10k patches, profiles/r05j_config3_kernel_stats.md)
+            for b in range(nbags):
+                landing = torch.empty((spr * n, L0), device=dev, dtype=torch.float32)
+                for i, (bag, sx_, lb_, st_) in enumerate(slides[b]):
+                    view = landing[i * n:(i + 1) * n]
+                    view.copy_(bag)
+                    slides[b][i] = (view, sx_, lb_, st_)
+                del bag
         global_slides = spr * world
         scaling = "weak"
     patches_per_rank_step = sum(int(sl[0].shape[0]) for sl in slides[0])
@@ -645,7 +657,9 @@ def main():
                                    f"{len(slides[0])} x {n}-patch x 1024-d N(0,1) fp32 bag(s) per GPU per step, bags resident in HBM"
                                    + (" in the ingest format (toad_bag_prepare_f32 BEFORE the timed region: both fp16 pieces of every fp32 element, plane-tiled, 4 B/element)"
                                       if prepared else " as raw fp32 tensors; measuring the bag (abs-max, inside the first GEMM) and splitting it into the GEMM operand pieces happen inside every timed step")
-                                   + (f"; 64 slides per optimiser step dealt round robin over {world} rank(s)" if args.config == 4 else ""),
+                                   + (f"; 64 slides per optimiser step dealt round robin over {world} rank(s)" if args.config == 4 else "")
+                                   + ("; the bags of a step lie back to back in one resident buffer (the layout toad_amd.ingest.BagPrefetcher(arena_rows=...) lands them in)"
+                                      if batched else ""),
                        "arithmetic": "fp32 storage/accumulation; GEMM operands as two fp16 pieces (x*s = h+m, power-of-two scales), 3 MFMA terms = "
                                      "fp32-equivalent, verified vs fp64 (tools/split_emulation.py, tests/test_gpu_h2.py)",
                        "patches_per_slide": n, "slides_per_step": global_slides,
