@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("script,cases,seed", [("fuzz_conv.py", 60, 11), ("fuzz_gemm.py", 24, 11), ("fuzz_pool.py", 40, 11),
-                                               ("fuzz_eval.py", 8, 11), ("fuzz_multi.py", 6, 11), ("fuzz_mil.py", 8, 11)])
+                                               ("fuzz_eval.py", 8, 11), ("fuzz_multi.py", 6, 11), ("fuzz_mil.py", 8, 11), ("fuzz_attn.py", 24, 11)])
 def test_random_shape_sweep(cuda, script, cases, seed):
     r = subprocess.run([sys.executable, os.path.join(HERE, script), str(cases), str(seed)], capture_output=True, text=True, timeout=850)
     tail = "\n".join((r.stdout + r.stderr).strip().splitlines()[-25:])
