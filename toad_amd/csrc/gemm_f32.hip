@@ -79,6 +79,7 @@ static void cfg() {
         TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 1>), H2_SMEM);
         TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 2>), H2_SMEM_PT);
         TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 3>), H2_SMEM_RUN);
+        TOAD_ATTR((gemm_nt_h2_big_kernel<true, false, 2, 4>), H2_SMEM);          // batched pooled addend (ragged multi-slide step)
         TOAD_ATTR(gemm_tn_h2_big_kernel<false>, TN2_SMEM);
         TOAD_ATTR(gemm_tn_h2_big_kernel<true>, TN2_SMEM);
         TOAD_ATTR(gemm_tn_pt_kernel, TP_SMEM);
@@ -292,7 +293,12 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
                        (int)N, (int)K, bias, es, addend, msrc, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, bits_out, tiles_m, tiles_n, a_stride, y_stride, (float *)nullptr, (int *)nullptr)
     const int msk = mask_bits ? 2 : (mask_src ? 1 : 0);
     if (mask_bits && !mask_src) { set_error("%s: the one-bit ReLU image needs the fp32 relu_src as well (remainder tiles)", what); return TOAD_EINVAL; }
-    if (pool.T > 0) { if (msk == 2) TOAD_LAUNCH_H2(true, false, 2); else if (msk == 1) TOAD_LAUNCH_H2(true, false, 1); else TOAD_LAUNCH_H2(true, false, 0); }
+    if (pool.T >> 8) {       // batched pooled addend: per-row records + per-slide dM (the ragged multi-slide step; gemm_h2_epilogue.inc PBATCH)
+        if ((pool.T & 255) != 2 || msk != 2 || !aligned16(pool.a_raw)) { set_error("%s: the batched pooled addend is instantiated for 2 tasks on the one-bit ReLU image", what); return TOAD_EINVAL; }
+        hipLaunchKernelGGL((gemm_nt_h2_big_kernel<true, false, 2, 4>), dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, a_amax, planes, binv, C, ldc, (int)M, (int)N, (int)K, bias,
+                           es, (const float *)nullptr, msrc, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, bits_out, tiles_m, tiles_n, a_stride, y_stride,
+                           (float *)nullptr, (int *)nullptr);
+    } else if (pool.T > 0) { if (msk == 2) TOAD_LAUNCH_H2(true, false, 2); else if (msk == 1) TOAD_LAUNCH_H2(true, false, 1); else TOAD_LAUNCH_H2(true, false, 0); }
     else if (addend) { if (msk == 2) TOAD_LAUNCH_H2(false, true, 2); else if (msk == 1) TOAD_LAUNCH_H2(false, true, 1); else TOAD_LAUNCH_H2(false, true, 0); }
     else { if (msk == 2) TOAD_LAUNCH_H2(false, false, 2); else if (msk == 1) TOAD_LAUNCH_H2(false, false, 1); else TOAD_LAUNCH_H2(false, false, 0); }
 #undef TOAD_LAUNCH_H2

@@ -504,9 +504,28 @@ extern "C" int toad_mil_step_xp_f32(const float *const *params, float *const *gr
 // (the caller folds 1/B into w_cls, w_site). Per-slide results: loss_out [B][3], logits_out [B][C], site_logits_out [B][2].
 // offsets: HOST array of B + 1 row offsets (offsets[0] = 0, offsets[B] = sum N_b); sex / label / site: DEVICE arrays of B.
 // Differences from B calls of toad_mil_step_f32, all at fp32 round-off level: GEMM operand scales are taken per 256-row block of
-// the CONCATENATION, and the pooling gradient dH_pool is materialised (per-slide softmax statistics cannot ride in one GEMM
-// epilogue) instead of being recomputed in the dgrad. Train-mode dropout masks hash the element index in the concatenation.
+// the CONCATENATION. Train-mode dropout masks hash the element index in the concatenation. (Until round 5 the pooling gradient dH_pool was
+// materialised here; the attention dgrad now recomputes it from per-row records, gemm_h2_epilogue.inc PBATCH.)
 namespace toad {
+// Per-row records of the batched pooled addend (gemm_h2_epilogue.inc PBATCH): rec[row] = {w0, w1, slide index as a bit pattern, 0} with
+// w_t = softmax weight of the row inside ITS slide = exp(A_raw[row, t] - max_t) / sum_t (models/model_toad.py:97). blockIdx.y = slide.
+__global__ __launch_bounds__(256) void pool_rowrec_kernel(const float *__restrict__ A_raw, const float *__restrict__ stats, int s_stride,
+                                                          const int64_t *__restrict__ seg, float *__restrict__ rec) {
+    const int b = blockIdx.y;
+    const int64_t r0 = seg[b], r1 = seg[b + 1];
+    const float *st = stats + (int64_t)b * s_stride;
+    const float m0 = st[0], i0 = 1.f / st[1], m1 = st[2], i1 = 1.f / st[3];
+    for (int64_t r = r0 + (int64_t)blockIdx.x * 256 + threadIdx.x; r < r1; r += (int64_t)gridDim.x * 256) {
+        const f32x2 a = *reinterpret_cast<const f32x2 *>(A_raw + 2 * r);
+        f32x4 v;
+        v[0] = __builtin_amdgcn_exp2f((a[0] - m0) * 1.4426950408889634f) * i0;
+        v[1] = __builtin_amdgcn_exp2f((a[1] - m1) * 1.4426950408889634f) * i1;
+        v[2] = __builtin_bit_cast(float, b);
+        v[3] = 0.f;
+        *reinterpret_cast<f32x4 *>(rec + 4 * r) = v;
+    }
+}
+
 struct MultiSmall { float *stats, *M, *Mcat, *logits, *yprob, *slog, *sprob, *dM, *dl, *dsv; int64_t *yhat, *shat, *seg; void *pool_ws; size_t total; };
 constexpr size_t kSlideRec = 8192;                  // bytes reserved per slide and per small array (>= T*(L+1)*4 = 4104, 256-B multiple)
 static MultiSmall multi_small_layout(int B, char *base) {
@@ -608,17 +627,27 @@ extern "C" int toad_mil_multi_step_f32(const float *const *params, float *const 
         set_error("%s: copying the per-slide site logits failed: %s", what, hipGetErrorString(hipGetLastError()));
         return TOAD_EINVAL;
     }
-    TOAD_TRY(launch_pool_bwd_batch(f.P, f.P + D, D2, f.H, p.wc, f.A_raw, ms.stats, rec_f, ms.M, ms.dM, rec_f, w.dP, w.dP + D, D2, w.dZ2, grads[6], grads[7], beta,
+    // (round 5: no dH_pool output any more - the attention dgrad below recomputes the pooling gradient per row from the records written here, like the
+    // one-slide step does from A_raw and its statistics: 410 MB less HBM traffic per 100k rows. The records live in dZ1's buffer behind the row bounds.)
+    float *rowrec = w.dZ1 + ((N + 3) & ~(int64_t)3);
+    TOAD_TRY(launch_pool_bwd_batch(f.P, f.P + D, D2, f.H, p.wc, f.A_raw, ms.stats, rec_f, ms.M, ms.dM, rec_f, w.dP, w.dP + D, D2, nullptr, grads[6], grads[7], beta,
                                    ms.pool_ws, ms.seg, B, max_n, kL, D, kT, drop_p, ds.sa, ds.sb, st, w.amax_dP, w.dZ1, N));
+    {
+        int64_t gx = (max_n + 255) / 256;
+        if (gx > 64) gx = 64;
+        hipLaunchKernelGGL(pool_rowrec_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, st, (const float *)f.A_raw, (const float *)ms.stats, rec_f,
+                           (const int64_t *)ms.seg, rowrec);
+        TOAD_TRY(check_launch(what));
+    }
     // (the slides' row ranges do not line up with the 256-row blocks of the concatenation: the pool backward leaves one upper bound of |dP| per ROW -
     // in dZ1's buffer, which nobody has written yet - and its reduce kernel folds 256 of them into each slot of dP's abs-max array. Round 3 measured
     // the array in a pass of its own over dP: 307 MB read per 100k rows.)
     // ---- backward GEMMs over all rows
     WgradDeferred dw[3];
     ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what, TOAD_X_F32, &dw[0])); ev(9);
-    // dZ2 = (dP Wab + dH_pool) * (H > 0), in place over the materialised dH_pool
-    ev(10); TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, w.dZ2, f.H, f.bits_h, nopool, w.slabs,
-                                  w.amax_dZ2, nullptr, st, what)); ev(11);
+    // dZ2 = (dP Wab + dH_pool) * (H > 0): dH_pool[row] = sum_t w_t(row) dM_t[slide(row)] recomputed in the epilogue (batched pooled addend)
+    ev(10); TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, nullptr, f.H, f.bits_h,
+                                  H2Pool{rowrec, nullptr, ms.dM, kT | (rec_f << 8)}, w.slabs, w.amax_dZ2, nullptr, st, what)); ev(11);
     ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws2, st, what, TOAD_X_F32, &dw[1])); ev(13);
     ev(14); TOAD_TRY(launch_nt_h2(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, f.bits_h1, nopool, w.slabs,
                                   w.amax_dZ1, nullptr, st, what)); ev(15);
