@@ -711,6 +711,29 @@ def main():
             out["prepared_resident"] = {"value": round(global_slides * 1e3 / pre_ms, 3), "unit": "slides/s", "ms_per_step": round(pre_ms, 3), "steps": args.steps,
                                         "what": "the step alone on bags converted BEFORE the timed region (toad_mil_step_xp_f32); the conversion it leaves out costs",
                                         "prepare_us_per_bag": time_prepare(n, dev)}
+        if world == 1 and args.config == 0 and len(slides[0]) == 1 and not prepared and args.bag_dtype == "fp32" and not args.no_prepared_legs:
+            # (d) the data-parallel trainer's own mode on the same bags: FIVE slides per optimiser step, landed back to back, through ONE ragged multi-slide
+            # call (toad_mil_multi_step_f32: 500k rows fill the 256 x 256 tile plan and the per-call helpers are paid once per five slides). `value` above
+            # stays the reference's semantics - one optimiser step per slide (utils/core_utils_mtl_concat.py:200-234).
+            k5 = 5
+            land = torch.empty((k5 * n, L0), device=dev, dtype=torch.float32)
+            five = []
+            for i in range(k5):
+                bag, sx_, lb_, st_ = make_slide(100 + i, n, dev, prepared=False)
+                land[i * n:(i + 1) * n].copy_(bag)
+                five.append((land[i * n:(i + 1) * n], sx_, lb_, st_))
+                del bag
+            for i in range(2):
+                dp.step(five, k5)
+            sync(); t3 = time.perf_counter()
+            k5_steps = max(4, args.steps // 4)
+            for i in range(k5_steps):
+                dp.step(five, k5)
+            sync(); b_ms = (time.perf_counter() - t3) / k5_steps * 1e3
+            del five, land
+            out["batched"] = {"value": round(k5 * 1e3 / b_ms, 3), "unit": "slides/s", "slides_per_step": k5, "ms_per_step": round(b_ms, 3), "steps": k5_steps,
+                              "what": "five 100k-patch slides per optimiser step through ONE ragged multi-slide call of 500k rows (SlideShardedDP's own batching; bags landed "
+                                      "back to back as BagPrefetcher(arena_rows=...) lands them); not `value`, which keeps one optimiser step per slide"}
         if world == 1 and args.config in (0, 3) and not args.no_dropin:
             k = max(args.steps, 10)
             ms = time_dropin(n, k, 3, dev, host_reads=False)

@@ -159,9 +159,10 @@ class SlideShardedDP:
     # 1.29 -> 1.17 ms per slide, profiles/r04d). Round 5 sized the call for 288 GB of HBM instead of for one tile-plan round: ten 50k-patch slides per call
     # (524,288 rows, ~8 GB of workspace) amortise the per-call helpers (weight split, five K-split fix-ups, slab reduction, heads) and the tile tail over
     # five times the rows: 935 -> 1,022 slides/s on config 4 (profiles/r05g_config4_batch_rows.txt). Both are constructor arguments. The per-slide
-    # threshold stays at 65,536: a 100k-patch slide fills the chip on its own and the batched call has to materialise the pooling gradient the
-    # per-slide call recomputes in its dgrad epilogue - five 100k-patch slides per call measured 459 slides/s against 461 one by one (profiles/r05i).
-    BATCH_MAX_PATCHES = 65536
+    # threshold followed once the batched attention dgrad recomputed the pooling gradient instead of reading a materialised one (csrc/step.hip,
+    # gemm_h2_epilogue.inc PBATCH): five 100k-patch slides in one call then run at 515 slides/s against 475 one by one on the same box
+    # (profiles/r05r_batched_100k.txt; with the materialised gradient it was 459 against 461).
+    BATCH_MAX_PATCHES = 262144
     BATCH_ROWS = 524288
 
     def accumulate(self, slides: Sequence[Slide], global_slides: int, overwrite: bool = True, batched: Optional[bool] = None):
