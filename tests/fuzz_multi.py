@@ -1,5 +1,5 @@
 """Random ragged batches through toad_mil_multi_step_f32 against the sum of the oracle's per-slide fp64 gradients (the third check of
-__graft_entry__.smoke() over many batch compositions). Not collected by pytest: `python tests/fuzz_multi.py [cases] [seed]` on a GPU box.
+__graft_entry__.smoke() over many batch compositions). Not collected by pytest: `python tests/fuzz_multi.py [cases] [seed] [big]` on a GPU box.
 Checked per case: all 14 parameter gradients (the stacked attention_a / attention_b weights and biases through the `wab` / `bab` slots, every
 bias slot) - 1e-3 of each gradient's scale for the trunk / attention weights (a ReLU-boundary flip may move them by one patch's contribution;
 then the rank-one test decides), 2e-5 .. 1e-4 for the mask-free head / attention-c gradients - and the per-slide losses and logits the call
@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import helpers
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+big = len(sys.argv) > 3 and sys.argv[3] == "big"      # up to 40 slides of up to 30,000 patches: many slide boundaries inside 256-row tiles, >= 512-tile launches
 rng = random.Random(seed)
 dev = torch.device("cuda:0")
 c = 18
@@ -31,8 +32,9 @@ KEYS = (("wcls", "classifier.weight", 2e-5), ("bcls", "classifier.bias", 2e-5), 
         ("b1", "attention_net.0.bias", 1e-3), ("wab", (A + "weight", B_ + "weight"), 1e-3), ("bab", (A + "bias", B_ + "bias"), 1e-3))
 nfail = 0
 for i in range(cases):
-    B = rng.randint(1, 12)
-    lens = [rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 300, 777, rng.randint(1, 2500)]) for _ in range(B)]
+    B = rng.randint(1, 40 if big else 12)
+    lens = [rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 300, 777, rng.randint(1, 2500)] + ([511, 513, 1023, 4097, rng.randint(1, 30000), rng.randint(1, 30000)] if big else []))
+            for _ in range(B)]
     bags = [torch.randn(m, 1024, generator=gen) for m in lens]
     labels = torch.tensor([rng.randrange(c) for _ in range(B)]); sites = torch.tensor([rng.randint(0, 1) for _ in range(B)])
     sexes = torch.tensor([float(rng.randint(0, 1)) for _ in range(B)])
@@ -59,7 +61,10 @@ for i in range(cases):
         if slot == "bc":                 # exactly zero by the softmax's shift invariance: what is returned is round-off of terms of dWc's size
             sc = max(sc, tot["attention_net.4.attention_c.weight"].abs().max().item())
         err = (g[slot].cpu().double() - ref).abs().max().item()
-        if err > tol * sc + 1e-12:
+        # head biases are SUMS over the batch of (softmax - onehot) * w / B: with many slides they cancel to far below the size of their terms, and what
+        # any fp32 summation returns is round-off of those terms (|term| <= w / B), not of the result: floor of 2e-6 of one term's bound per sqrt(B)
+        floor = {"bcls": 2e-6 * 0.75, "bsite": 2e-6 * 0.25}.get(slot, 0.0) / max(B, 1) ** 0.5
+        if err > tol * sc + floor + 1e-12:
             # a trunk gradient may differ by a few LEGITIMATE ReLU-boundary flips: rank-one terms of one patch's size (tests/helpers.py);
             # the bias of a layer then moves by that patch's dZ element, allowed only when the layer's weight gradient showed the flip
             try:
