@@ -144,7 +144,9 @@ def _probe_threads(once, budget_s: float, min_reps: int):
     (median of >= min_reps) - the baseline is the best this CPU path can do on this box within a bounded sample."""
     logical = os.cpu_count() or 1
     phys = min(_physical_cores(), logical)
-    cands = [t for t in (32, 16, 64, phys, 8) if t <= max(phys, 4)]
+    # (hosts with >= 64 physical cores: 64 threads are probed before 16 - on a 128-core EPYC the 10 s probe budget used to end after {32, 16})
+    order = (32, 64, 16, phys, 8) if phys >= 64 else (32, 16, 64, phys, 8)
+    cands = [t for t in order if t <= max(phys, 4)]
     cands = list(dict.fromkeys(cands)) or [max(1, phys)]
     probe = {}
     t_start = time.perf_counter()
@@ -304,6 +306,66 @@ def time_prepared_pipelined(dp, raw_slides, global_slides: int, steps: int, warm
     return (time.perf_counter() - t0) / steps
 
 
+def time_ingest(dp, n: int, dev, slides_per_leg: int = 12):
+    """SURVEY.md 8(f) row 2 / the reference's loader (datasets/dataset_mtl_concat.py:369-373 `torch.load`, utils/core_utils_mtl_concat.py:201 `.to(device)`):
+    bags that arrive from HOST memory. `slides_per_leg` 100k-patch bags cycle through four page-locked host buffers and toad_amd.ingest.BagPrefetcher
+    (depth 2: the host-to-device copy of bag i+1 runs on its own HIP stream while step i computes) into the headline step (one optimiser step per
+    slide). Two wire formats: fp32 (410 MB per bag) and fp16 (205 MB; handed to the model as fp16: toad_mil_step_x16_f32). Beside each: the copy
+    alone (the link's rate on this box) and the step alone on resident bags, from which
+        overlap = (t_copy + t_step - t_pipelined) / min(t_copy, t_step)      (1 = the shorter of the two is fully hidden, 0 = serial).
+    Never `value`: the headline's bags are resident (bench contract); this is the rate a training run fed over PCIe sees."""
+    from toad_amd.ingest import BagPrefetcher
+    out = {}
+    nbuf = 4
+    for wire, dt in (("fp32", torch.float32), ("fp16", torch.float16)):
+        host = []
+        for i in range(nbuf):
+            bag, sx_, lb_, st_ = make_slide(200 + i, n, dev, prepared=False)
+            hb = torch.empty((n, L0), dtype=dt, pin_memory=True)
+            hb.copy_(bag.to(dt))
+            host.append(hb)
+            del bag
+        torch.cuda.synchronize()
+        nbytes = host[0].numel() * host[0].element_size()
+        # the copy alone (pinned -> device, one stream)
+        land = torch.empty((n, L0), dtype=dt, device=dev)
+        for _ in range(2):
+            land.copy_(host[0], non_blocking=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(slides_per_leg):
+            land.copy_(host[i % nbuf], non_blocking=True)
+        torch.cuda.synchronize(); t_copy = (time.perf_counter() - t0) / slides_per_leg
+        # the step alone on the landed bag
+        sx_, lb_, st_ = torch.tensor([1.0], device=dev), torch.tensor([3], device=dev), torch.tensor([1], device=dev)
+        for _ in range(2):
+            dp.step([(land, sx_, lb_, st_)], 1)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(slides_per_leg):
+            dp.step([(land, sx_, lb_, st_)], 1)
+        torch.cuda.synchronize(); t_step = (time.perf_counter() - t0) / slides_per_leg
+        del land
+
+        def run(k):                                           # the pipeline: BagPrefetcher(depth 2) feeding the step
+            recs = [(host[i % nbuf], i % C, i % 2, float((i // 2) % 2)) for i in range(k)]
+            for bag, lb, st, sx in BagPrefetcher(recs, dev, depth=2, workers=2, dtype=dt):
+                dp.step([(bag, sx, lb, st)], 1)
+        run(3)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        run(slides_per_leg)
+        torch.cuda.synchronize(); t_pipe = (time.perf_counter() - t0) / slides_per_leg
+        ov = (t_copy + t_step - t_pipe) / max(min(t_copy, t_step), 1e-9)
+        out[wire] = {"value": round(1.0 / t_pipe, 2), "unit": "slides/s", "ms_per_slide": round(t_pipe * 1e3, 3), "slides": slides_per_leg,
+                     "bytes_per_bag": nbytes, "h2d_gbps_in_pipeline": round(nbytes / t_pipe / 1e9, 1),
+                     "copy_alone": {"ms": round(t_copy * 1e3, 3), "gbps": round(nbytes / t_copy / 1e9, 1)},
+                     "step_alone_ms": round(t_step * 1e3, 3), "overlap": round(max(0.0, min(1.0, ov)), 3),
+                     "bound": "host-to-device link" if t_copy >= t_step else "compute"}
+        del host
+    out["what"] = ("100k-patch bags from page-locked host memory through toad_amd.ingest.BagPrefetcher(depth=2) into one optimiser step per slide "
+                   "(datasets/dataset_mtl_concat.py:369-373 + utils/core_utils_mtl_concat.py:201 in the reference); fp16 = features stored as fp16, taken "
+                   "by the fp16-bag kernels without an up-cast pass; copy_alone = the pinned host-to-device rate of this box; not `value` (resident bags)")
+    return out
+
+
 def time_dropin(n: int, steps: int, warmup: int, dev, host_reads: bool):
     """The reference's train_loop body (utils/core_utils_mtl_concat.py:201-234) on the drop-in module, resident bags.
     host_reads adds what the reference's loop reads back per slide (two loss .item(), Y_hat / site_hat for the loggers)."""
@@ -448,6 +510,9 @@ def main():
     ap.add_argument("--dropin", action="store_true", help="time only the reference's call sequence on the drop-in module")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="headline run without the extra drop-in timing")
+    ap.add_argument("--no-ingest", action="store_true", help="headline run without the host-memory ingest legs (fp32 / fp16 bags over PCIe through BagPrefetcher)")
+    ap.add_argument("--ingest-slides", type=int, default=12, help="slides per ingest leg")
+    ap.add_argument("--no-per-slide", action="store_true", help="--config 3 without the per_slide leg (one optimiser step per 10k-patch slide: the reference's own semantics)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--ragged", action="store_true",
                     help="config 4 only: log-normal slide lengths (same 64 x 50k = 3.2 M patches in total, sigma 0.7, seeded) dealt with "
@@ -575,7 +640,10 @@ def main():
     # Timed region: only the dominant HBM-bound kernel (the fused pool forward) is bracketed by HIP events (2 pre-created events
     # per library call). Bracketing all eight GEMM calls as well costs 18 event packets per call (~0.1 ms of stream time: 4 % of a
     # 100k-patch step, 2x of a 256-patch step), so the GEMM breakdown is measured in its own instrumented loop right after.
-    ops.enable_timing(True, level=1, prealloc=2 * args.steps * len(slides[0]))
+    # (every call of a 100k-patch step is bracketed, as the contract's "events over the timed region" reads; for short bags every 4th call: two event
+    #  packets cost ~11 us of stream time, 0.5 % of the headline step but 3 % of a 10k-patch one - profiles/r06a_*)
+    ev_stride = 1 if patches_per_rank_step >= 50_000 else 4
+    ops.enable_timing(True, level=1, prealloc=2 * args.steps * len(slides[0]), stride=ev_stride)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -585,6 +653,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     timing = ops.collect_timing()
+    timed_calls = ops.timing_call_count()                  # library calls of the timed region (every ev_stride-th one carried events)
     k_instr = min(args.steps, 10)
     ops.enable_timing(True, level=2, prealloc=18 * k_instr * len(slides[0]))
     for i in range(k_instr):
@@ -632,6 +701,9 @@ def main():
                     "allreduce_us": [round(r[2], 2) for r in rows], "patches_per_step": [int(r[3]) for r in rows],
                     "what": "step_ms = a rank's own wall time per step up to its local synchronize (before the closing barrier); ms_per_step of "
                             "the line is the max over ranks including the barrier"}
+        # what a first real multi-GPU run needs to attribute lost scaling without a re-run: the fastest rank's own step time over the job's
+        # step time (max over ranks, closing barrier included). 1.0 = nobody waited; the gap is imbalance + collective + barrier skew.
+        per_rank["scaling_efficiency_vs_per_rank_min"] = round(per_rank["step_ms_min"] / (elapsed / args.steps * 1e3), 4)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -673,7 +745,7 @@ def main():
         if "pool_fwd" in timing:
             calls, tot_ms = timing["pool_fwd"]
             pool_t = tot_ms / calls * 1e-3
-            calls_per_step = calls / args.steps                          # per-slide calls: slides per rank; ragged batch call: 1
+            calls_per_step = timed_calls / args.steps                    # per-slide calls: slides per rank; ragged batch call: 1
             slides_per_call = len(slides[0]) / calls_per_step
             # one launch pools every slide of the call (blockIdx.y = slide); ragged slides: the bytes of this rank's rows, per call on average
             pool_bytes = pool_fwd_bytes(n) * slides_per_call if ragged_lens is None else pool_fwd_bytes(patches_per_rank_step) / calls_per_step
@@ -734,6 +806,30 @@ def main():
             out["batched"] = {"value": round(k5 * 1e3 / b_ms, 3), "unit": "slides/s", "slides_per_step": k5, "ms_per_step": round(b_ms, 3), "steps": k5_steps,
                               "what": "five 100k-patch slides per optimiser step through ONE ragged multi-slide call of 500k rows (SlideShardedDP's own batching; bags landed "
                                       "back to back as BagPrefetcher(arena_rows=...) lands them); not `value`, which keeps one optimiser step per slide"}
+        if world == 1 and args.config == 0 and len(slides[0]) == 1 and not prepared and args.bag_dtype == "fp32" and not args.no_ingest:
+            out["ingest"] = time_ingest(dp, n, dev, args.ingest_slides)
+        if world == 1 and args.config == 3 and len(slides[0]) > 1 and not args.no_per_slide:
+            # the reference's own training semantics on this bag size: ONE optimiser step per slide (utils/core_utils_mtl_concat.py:200-234; its loaders
+            # are batch_size = 1, utils/utils.py:51-55). `value` above is the data-parallel trainer's mode (a rank's slides share one ragged call).
+            one = [[make_slide(300 + b, n, dev, prepared=False)] for b in range(2)]
+            for i in range(10):
+                dp.step(one[i % 2], 1)
+            k1 = max(10 * args.steps, 200)
+            sync(); t4 = time.perf_counter()
+            for i in range(k1):
+                dp.step(one[i % 2], 1)
+            sync(); ps_ms = (time.perf_counter() - t4) / k1 * 1e3
+            ops.enable_timing(True, level=2, prealloc=18 * 10)
+            for i in range(10):
+                dp.step(one[i % 2], 1)
+            tg = ops.collect_timing()
+            ops.enable_timing(False)
+            del one
+            out["per_slide"] = {"value": round(1e3 / ps_ms, 1), "unit": "slides/s", "ms_per_step": round(ps_ms, 4), "steps": k1, "slides_per_step": 1,
+                                "roofline_mfma_frac": gemm_roofline(tg, 10 * n)["frac"],
+                                "op_us_per_slide": {k_: round(v[1] / 10 * 1e3, 1) for k_, v in tg.items()},
+                                "what": "one optimiser step per 10,000-patch slide (toad_mil_step_f32 + toad_adam_step_f32): the reference's train_loop "
+                                        "semantics; no event packets inside the timed loop"}
         if world == 1 and args.config in (0, 3) and not args.no_dropin:
             k = max(args.steps, 10)
             ms = time_dropin(n, k, 3, dev, host_reads=False)

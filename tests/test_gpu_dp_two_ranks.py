@@ -3,7 +3,8 @@ RCCL refuses two ranks on one device; the driver's 8-GPU run uses backend "nccl"
 hip_slide_grad (toad_mil_step_f32) on its shard, then SlideShardedDP.step with the flat HIP Adam. Checks:
   (i)   both ranks end with bitwise identical parameters and reduced gradients;
   (ii)  the parameters equal a single-process run over the same slides (the gradient bucket up to the summation order of the two
-        partial sums: 1e-6 of its scale; 2e-5 on parameters after two Adam steps);
+        partial sums and of the two tile plans: 2e-6 of each gradient's scale, trunk gradients up to a legitimate ReLU flip; 2e-5 on
+        parameters after two Adam steps);
   (iii) the reduced gradient is the mean of the per-slide ORACLE gradients (the DP parity definition).
 Also exercises length-balanced sharding (shard_by_length) on the GPU.
 What is NOT reproduced, by design: the reference's intra-bag nn.DataParallel (models/model_toad.py:79-81)."""
@@ -89,7 +90,19 @@ def test_two_ranks_on_the_real_kernels(cuda, balanced):
     dp.step(slides, len(LENS))
     g_single = dp.flat_grad.cpu().clone()
     dp.step(slides, len(LENS))
-    assert (g_single - g0).abs().max().item() <= 1e-6 * max(g_single.abs().max().item(), 1e-30) + 1e-9
+    # The two-rank run concatenates two slides per ragged call, the single process all four: the calls differ in their 256-row operand blocks and -
+    # since round 6 - in tile plan (2.3k rows: K-split 256-row tiles; 4.6k rows: whole-K half-height tiles, csrc/gemm_f32.hip nt_half_tiles), i.e. in
+    # summation order. The ten gradients no ReLU mask reaches agree to 2e-6 of their scale; a trunk gradient may in addition differ by the rank-one
+    # contribution of a patch whose pre-activation sits at round-off of zero and fell on the other side of the ReLU (helpers).
+    from tests.helpers import assert_grad_close_or_few_flips
+    offs_chk, _ = model.flat_offsets()
+    for slot, (o, n) in offs_chk.items():
+        a, b = g0[o:o + n].view_as(model._slot_params()[slot]), g_single[o:o + n].view_as(model._slot_params()[slot])
+        sc = max(b.abs().max().item(), 1e-30)
+        if slot in ("w1", "b1", "w2", "b2"):
+            assert_grad_close_or_few_flips(a, b, 2e-6, sc, what=f"two ranks vs one process: {slot}", floor=1e-9)
+        else:
+            assert_grad_close(a, b, 2e-6, sc, what=f"two ranks vs one process: {slot}", floor=1e-9)
     # two Adam steps at lr 1e-3: Adam's update is ~lr * g/|g|, so a round-off-level gradient difference (summation order of the two
     # partial buckets) on a near-zero gradient can move that one parameter by up to lr per step. Hold almost all parameters tight and
     # every parameter inside what two sign flips can do. (The default kernels keep ALL within 2e-5; the TOAD_GEMM_H2=0 arm does not.)

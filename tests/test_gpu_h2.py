@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import toad_oracle as orc
-from tests.helpers import assert_grad_close, grad_scale
+from tests.helpers import assert_grad_close, assert_step_grad_matches_per_op, grad_scale
 
 pytestmark = pytest.mark.gpu
 
@@ -139,7 +139,9 @@ def _model_and_bag(cuda, n, c=18, seed=0, dropout=False):
 @pytest.mark.parametrize("n,drop", [(1, 0.0), (300, 0.0), (777, 0.25), (9000, 0.0)])
 def test_whole_slide_calls_are_bitwise_the_per_op_path(cuda, n, drop):
     """toad_mil_fwd_f32 / toad_mil_bwd_f32 (one C call each, what model(data, sex) / loss.backward() run) == the per-op
-    sequence of functional.mil_forward / mil_backward: same kernels, same order -> bitwise-equal outputs and gradients."""
+    sequence of functional.mil_forward / mil_backward: same kernels, same order -> bitwise-equal outputs and gradients.
+    Short bags: the three trunk / attention weight gradients of the whole-slide call share ONE launch with its own row splits, so those six
+    tensors agree with the per-op calls to summation round-off instead (helpers.assert_step_grad_matches_per_op)."""
     from toad_amd import functional as F_, ops
     model, _, x = _model_and_bag(cuda, n, seed=n)
     w = {k: v.detach() for k, v in model._weights().items()}
@@ -162,7 +164,7 @@ def test_whole_slide_calls_are_bitwise_the_per_op_path(cuda, n, drop):
     d = w["wa"].shape[0]
     ref = dict(g_ref); ref["wab"] = torch.cat([g_ref["wa"], g_ref["wb"]], 0); ref["bab"] = torch.cat([g_ref["ba"], g_ref["bb"]], 0)
     for k in ops.STEP_SLOTS:
-        assert torch.equal(grads[k], ref[k]), k
+        assert_step_grad_matches_per_op(grads[k], ref[k], k, n)
     assert torch.equal(dx, dx_ref) and torch.equal(dsex, dsex_ref)
     # attention_only stops after the scores
     a_only = ops.mil_fwd(w, xg, None, drop, seed, attention_only=True).view("a_raw", (n, 2))

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import toad_oracle as orc
-from tests.helpers import (LAYER2_KEYS, MASK_FREE_KEYS, SLOT2KEY, assert_grad_close, case_inputs, check_activations_vs_golden,
+from tests.helpers import (LAYER2_KEYS, MASK_FREE_KEYS, SLOT2KEY, assert_grad_close, assert_step_grad_matches_per_op, case_inputs, check_activations_vs_golden,
                            check_outputs_vs_golden, check_trunk_grads_vs_golden_blocks, grad_scale, relu_flip_positions)
 
 pytestmark = pytest.mark.gpu
@@ -235,9 +235,12 @@ def test_full_size_properties_100k(cuda):
 
 
 def test_million_patch_bag_duplication_property(cuda):
-    """Maximum size: a 1.1 M-patch bag (4.5 GB, M*K*4 >= 2^32: beyond the 32-bit-offset fast path of the persistent GEMMs, so the
-    64-bit generic kernels serve it). Property: repeating every row r times leaves the softmax-pooled features, the logits
-    and - because each copy carries 1/r of the attention - all gradients unchanged."""
+    """Maximum size: a 1.1 M-patch bag (4.5 GB, M*K*4 >= 2^32: beyond the 32-bit row offsets of the persistent NT GEMMs, which therefore run over
+    ROW CHUNKS of 1,047,552 rows - csrc/step.hip nt_rows; until round 5 the 64-bit generic kernels served it). Property: repeating every row r
+    times leaves the softmax-pooled features, the logits and - because each copy carries 1/r of the attention - all gradients unchanged.
+    Then the same bag in TRAIN mode with dropout: chunk j > 0 draws its trunk masks from the stream seed + j * kChunkSeedStep at the chunk-local
+    element index (nothing else reproduces that, so it is pinned here): the second chunk's H1 / H must be zero exactly where the exported masks of
+    those streams are zero, and the fused step (toad_mil_step_f32) must give the gradients of forward + loss + backward as separate calls."""
     from toad_amd import TOAD_fc_mtl_concat
     params = orc.xavier_params(18, seed=2)
     m = TOAD_fc_mtl_concat(n_classes=18); m.load_state_dict(params); m.relocate(); m.train()
@@ -258,6 +261,38 @@ def test_million_patch_bag_duplication_property(cuda):
     assert (out_b["A"][:, :1100] - out_s["A"]).abs().max().item() <= 1e-4
     for k in g_s:       # 1e-4 absolute: the two sizes run on different kernels, so ReLU-boundary flips differ
         assert (g_b[k] - g_s[k]).abs().max().item() <= 1e-4, k
+    del out_b, g_b
+    # ---- train-mode dropout above the chunk size
+    from toad_amd import functional as F_, ops
+    big = small.repeat(1000, 1)
+    n, chunk, step_c, M64 = big.shape[0], 4092 * 256, 0xD1B54A32D192ED03, 0xFFFFFFFFFFFFFFFF          # csrc/step.hip kChunkRows, kChunkSeedStep
+    w = {k: v.detach() for k, v in m._weights().items()}
+    drop, seed = 0.25, 987654321
+    arena = ops.mil_fwd(w, big, sex, drop, seed)
+    s1, s2, _, _ = F_.drop_seeds(seed)
+    rows1 = n - chunk
+    for name, sd in (("h1", s1), ("h", s2)):
+        act = arena.view(name, (n, 512))
+        mk1 = ops.dropout_mask(rows1 * 512, drop, (sd + step_c) & M64, cuda).reshape(rows1, 512)      # chunk 1: its own stream, chunk-local index
+        c1 = act[chunk:]
+        assert (c1[mk1 == 0] == 0).all(), name
+        kept = (c1 != 0) & (mk1 > 0)
+        assert 0.2 < kept.float().mean().item() < 0.6, name                                          # ~ 0.75 x P(relu > 0)
+        mk0 = ops.dropout_mask(4096 * 512, drop, sd, cuda).reshape(4096, 512)                         # chunk 0: the bag-wide stream
+        assert (act[:4096][mk0 == 0] == 0).all(), name
+        # chunk 1 does NOT continue chunk 0's stream (that would be index (chunk + r) * 512 + c of the stream `sd`): its zero pattern differs from it
+        assert not torch.equal(mk1[:4096] == 0, mk0 == 0), name
+        del act, mk1, c1, kept, mk0
+    outs_logits = arena.view("logits", (1, 18)).clone(); outs_slog = arena.view("site_logits", (1, 2)).clone()
+    lossv, dl, ds = ops.mtl_ce_fwd_bwd(outs_logits, outs_slog, label, site, 0.75, 0.25)
+    g_sep = {k: torch.zeros_like(w[k]) for k in ops.STEP_SLOTS}
+    ops.mil_bwd(w, g_sep, 0.0, big, arena, dl, ds, None, None, drop, seed)
+    del arena
+    g_fused = {k: torch.zeros_like(w[k]) for k in ops.STEP_SLOTS}
+    loss2, _, _ = ops.mil_step(w, g_fused, 0.0, big, sex, label, site, 0.75, 0.25, drop, seed)
+    assert torch.equal(loss2, lossv)
+    for k in ops.STEP_SLOTS:
+        assert torch.equal(g_fused[k], g_sep[k]), k
 
 
 def test_non_default_stream_and_autograd_thread(cuda):
@@ -319,6 +354,50 @@ def test_attn_net_gated_standalone(cuda, shape):
             net.attention_c.weight, net.attention_c.bias]
     for p, r in zip(mine, prm):        # smooth (no ReLU): rounding only, 1e-4 of each gradient's own scale
         assert_grad_close(p.grad, r.grad, 1e-4, float(r.grad.abs().max()))
+    assert_grad_close(xg.grad, xr.grad, 1e-4, float(xr.grad.abs().max()))
+
+
+def test_attn_net_gated_dropout_column_blocks_draw_independent_masks(cuda):
+    """Standalone Attn_Net_Gated(dropout=True) with D > 512 (models/model_toad.py:19-41 take any D): the gate columns run as blocks of <= 512, each
+    block and each BRANCH (tanh / sigmoid) on a mask stream of its own - block j uses (sa + 2 j G, sb + 2 j G), sb = sa + G. (Round 5 stepped the
+    blocks by G: block j + 1's tanh masks were block j's sigmoid masks.) The device masks are exported per stream (toad_dropout_mask_f32, element
+    index row * block_width + column), shown to be pairwise different, and fed to autograd on the reference formula: forward scores and every
+    gradient must agree."""
+    from toad_amd import Attn_Net_Gated, functional as F_, ops
+    l, d, t, n = 512, 1100, 2, 700
+    torch.manual_seed(11)
+    net = Attn_Net_Gated(L=l, D=d, dropout=True, n_tasks=t).to(cuda)
+    net.train()
+    x = torch.randn(n, l)
+    xg = x.to(cuda).requires_grad_(True)
+    torch.manual_seed(77)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # what _draw_dropout will draw next
+    torch.manual_seed(77)
+    a, _ = net(xg)
+    _, _, sa, sb = F_.drop_seeds(seed)
+    G, M64 = 0x9E3779B97F4A7C15, 0xFFFFFFFFFFFFFFFF
+    blocks = [(0, 512), (512, 1024), (1024, 1100)]
+    ma, mb, streams = torch.empty(n, d), torch.empty(n, d), []
+    for j, (d0, d1) in enumerate(blocks):
+        wd = d1 - d0
+        ka = ops.dropout_mask(n * wd, F_.DROP_P, (sa + 2 * j * G) & M64, cuda).reshape(n, wd).cpu()
+        kb = ops.dropout_mask(n * wd, F_.DROP_P, (sb + 2 * j * G) & M64, cuda).reshape(n, wd).cpu()
+        ma[:, d0:d1], mb[:, d0:d1] = ka, kb
+        streams += [ka, kb]
+    for i in range(4):                                           # the four 512-wide streams (two blocks x two branches) are pairwise different
+        for k in range(i + 1, 4):
+            assert (streams[i] != streams[k]).float().mean().item() > 0.2, (i, k)
+    prm = [p_.detach().cpu().clone().requires_grad_(True) for p_ in (net.attention_a[0].weight, net.attention_a[0].bias, net.attention_b[0].weight,
+                                                                     net.attention_b[0].bias, net.attention_c.weight, net.attention_c.bias)]
+    xr = x.clone().requires_grad_(True)
+    ga = torch.tanh(torch.addmm(prm[1], xr, prm[0].t())) * ma      # nn.Dropout after Tanh / Sigmoid (model_toad.py:27-29): mask = 0 or 1 / (1 - p)
+    gb = torch.sigmoid(torch.addmm(prm[3], xr, prm[2].t())) * mb
+    ref = torch.addmm(prm[5], ga * gb, prm[4].t())
+    assert (a.detach().cpu() - ref.detach()).abs().max().item() <= 2e-5
+    a.sin().sum().backward(); ref.sin().sum().backward()
+    mine = [net.attention_a[0].weight, net.attention_a[0].bias, net.attention_b[0].weight, net.attention_b[0].bias, net.attention_c.weight, net.attention_c.bias]
+    for p_, r in zip(mine, prm):
+        assert_grad_close(p_.grad, r.grad, 1e-4, float(r.grad.abs().max()))
     assert_grad_close(xg.grad, xr.grad, 1e-4, float(xr.grad.abs().max()))
 
 
@@ -462,7 +541,7 @@ def test_fused_step_entry_is_bitwise_the_per_op_path(cuda, n, drop):
     d = w["wa"].shape[0]
     ref = dict(g); ref["wab"] = torch.cat([g["wa"], g["wb"]], 0); ref["bab"] = torch.cat([g["ba"], g["bb"]], 0)
     for k in ops.STEP_SLOTS:
-        assert torch.equal(dest[k], ref[k]), k
+        assert_step_grad_matches_per_op(dest[k], ref[k], k, n)
     ops.mil_step(w, dest, 1.0, x, sex, label, site, 0.75, 0.25, drop, seed)       # accumulate on top
     for k in ops.STEP_SLOTS:
         assert (dest[k] - 2 * ref[k]).abs().max().item() <= 1e-6 * max(ref[k].abs().max().item(), 1.0), k

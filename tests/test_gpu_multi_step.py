@@ -119,12 +119,18 @@ def _step_workspace_activations(n, nb, c, d, dev):
 #   (a) staggered workgroup starts of the persistent NT GEMMs (csrc/gemm_f32.hip launch_nt_h2: es.stagger for launches of >= 512 tiles);
 #   (b) dP's abs-max array taken from the per-row |dP| bound the batched pool backward leaves in dZ1's buffer, folded 256 rows per slot
 #       (csrc/step.hip: launch_pool_bwd_batch(..., w.amax_dP, w.dZ1, N)) - slide boundaries off the 256-row grid matter here;
-#   (c) the attention dgrad on the one-bit ReLU image with a materialised addend (gemm_nt_h2_big_kernel<true, false, 2, 0>).
+#   (c) the attention dgrad on the one-bit ReLU image with the BATCHED pooled addend recomputed per row from records {w0, w1, slide} and the slides'
+#       dM (gemm_nt_h2_big_kernel<true, false, 2, 4>, gemm_h2_epilogue.inc PBATCH; round 4 read a materialised addend through <true, false, 2, 0>).
 # Reference semantics: utils/core_utils_mtl_concat.py:200-234, one forward / loss / backward per slide; the batch gradient is their sum.
 BIG_BATCHES = [("config4_pair", [50000, 50000], 0.0), ("batch_rows_limit", [65536, 65536], 0.0), ("off_grid_boundaries", [50000, 30001, 20000], 0.0),
                ("dropout_70k_rows", [40000, 30001], 0.25),
                # round 5 raised the default call size to 524,288 rows (toad_amd/dp.py BATCH_ROWS: ten 50k-patch slides per call): one batch of exactly that size
-               ("default_call_size_524288_rows", [100000, 50000, 50000, 100000, 100000, 100000, 24288], 0.0)]
+               ("default_call_size_524288_rows", [100000, 50000, 50000, 100000, 100000, 100000, 24288], 0.0),
+               # ... and the per-slide limit to 262,144 patches (BATCH_MAX_PATCHES): both limits at once; the extremes `bench.py --config 4 --ragged` sends
+               # through the call (197k- and 9k-patch slides, boundaries off the 256-row grid); a slide above 100k patches under train-mode dropout
+               ("both_limits_2x262144", [262144, 262144], 0.0),
+               ("ragged_extremes_197k_9k_131k", [197000, 9000, 131072], 0.0),
+               ("dropout_slide_above_100k", [120001, 30000], 0.25)]
 
 
 @pytest.mark.parametrize("name,lens,drop_p", BIG_BATCHES, ids=[b[0] for b in BIG_BATCHES])

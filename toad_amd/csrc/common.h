@@ -103,6 +103,7 @@ struct H2Operand { const float *src; int64_t sn, sk; int64_t N, K; unsigned shor
 struct H2Pool { const float *a_raw, *stats, *dM; int T; };                                                   // recomputed pooling addend (T = 0: none)
 struct EpiScalars { int relu; float mask_scale; DropArgs drop; int stagger = 0; };                           // epilogue scalars of every NT kernel; stagger: gemm_h2.inc
 bool h2_nt_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc);
+bool nt_half_tiles(int64_t M, int64_t N);               // fp32-A products of this shape run on half-height tiles (no K-split: every tile writes / reads the ReLU bit image)
 bool nt_run_ok(int64_t M, int64_t N, int64_t K);       // the first GEMM may measure its fp32 A operand itself (gemm_h2.inc AMODE 3)
 size_t h2_planes_bytes(int64_t N, int64_t K);
 size_t h2_binv_bytes(int64_t N);
@@ -157,5 +158,11 @@ int launch_wgrad(const float *dY, const float *dy_amax, const float *X, const fl
 // a weight gradient whose slab reduction was deferred (launch_wgrad with `defer`): up to three are reduced by ONE launch_wgrad_reduce
 struct WgradDeferred { const float *slab; float *out; int64_t n; const float *slab2; float *out2; int64_t n2; int nsplit; float beta; const float *scales; };
 int launch_wgrad_reduce(const WgradDeferred *d, int count, hipStream_t st, const char *what);
+// two or three weight gradients over the SAME M rows in one launch (gemm_tn_h2_batch_kernel): fp32 operands with their abs-max arrays, one slab
+// area (toad_linear_wgrad_ws_bytes) each; always deferred - the caller reduces them with launch_wgrad_reduce
+constexpr int64_t kTnBatchMaxRows = 32768;
+struct WgradJob { const float *dY, *dy_amax, *X, *x_amax; float *dW, *db; int64_t N, K; void *ws; };
+bool wgrad_batch_ok(int64_t M, const WgradJob *jobs, int n, size_t ws_bytes_each);
+int launch_wgrad_batch(const WgradJob *jobs, int n, int64_t M, float beta, hipStream_t st, const char *what, WgradDeferred *defer);
 
 }  // namespace toad

@@ -80,8 +80,15 @@ static void cfg() {
         TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 2>), H2_SMEM_PT);
         TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 3>), H2_SMEM_RUN);
         TOAD_ATTR((gemm_nt_h2_big_kernel<true, false, 2, 4>), H2_SMEM);          // batched pooled addend (ragged multi-slide step)
+        // half-height tiles (short operands; nt_half_tiles below): the MIL step's five epilogues
+        TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 0, 128>), H2_SMEM);
+        TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 2, 0, 128>), H2_SMEM);
+        TOAD_ATTR((gemm_nt_h2_big_kernel<true, false, 2, 0, 128>), H2_SMEM);
+        TOAD_ATTR((gemm_nt_h2_big_kernel<true, false, 2, 4, 128>), H2_SMEM);
+        TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 3, 128>), H2_SMEM_RUN);
         TOAD_ATTR(gemm_tn_h2_big_kernel<false>, TN2_SMEM);
         TOAD_ATTR(gemm_tn_h2_big_kernel<true>, TN2_SMEM);
+        TOAD_ATTR(gemm_tn_h2_batch_kernel, TN2_SMEM);
         TOAD_ATTR(gemm_tn_pt_kernel, TP_SMEM);
         TOAD_ATTR(gemm_nt_f32_kernel, NT_SMEM);
         TOAD_ATTR(gemm_tn_f32_kernel, TN_SMEM);
@@ -186,6 +193,26 @@ size_t h2_planes_bytes(int64_t N, int64_t K) { return (size_t)((N + PB - 1) / PB
 size_t h2_slab_bytes() { return (size_t)PB_GRID * PB * PB * sizeof(float); }
 size_t h2_binv_bytes(int64_t N) { return (size_t)((N + PB - 1) / PB) * PB * sizeof(float); }
 
+// Half-height (128 x 256) tiles, one whole-K item per workgroup and no K-split / fix-up launch (gemm_h2.inc, TM = 128): for operands short enough
+// that every XCD holds at most 32 such tiles AND long enough that the 256 x 256 plan could only cut its tiles into two K-slices (its cap of ~64
+// slabs per launch, nt_plan): measured on the 10k-patch step (profiles/r06c_*), a two-slice GEMM + its fix-up launch take 46 / 52 / 63 us
+// (K = 512 / 768 / 1024) against 33 / 47 / 62 us for whole-K half tiles (a 128-row stage costs 1.8 us, the LOAD phase of a wave bounds it, a
+// 256-row stage 2.1). Shorter operands (a 2,000-patch bag: three or more slices per tile, a 256-patch bag: sixteen one-stage slices) stay on the
+// K-split, which puts more CUs on them than whole-K items would.
+// The rule depends on (M, N) ONLY, never on K: the one-bit ReLU image a forward GEMM writes (whole tiles only; K-split remainder tiles go through
+// the fix-up kernel, which reads the fp32 activations instead) is read by the dgrad of the same layer, a GEMM with the same M and N and another
+// K - both must agree on which tiles are whole.
+bool nt_half_tiles(int64_t M, int64_t N) {
+    const int tiles_n = (int)((N + PB - 1) / PB);
+    const int64_t tm128 = (M + 127) / 128, tm256 = (M + PB - 1) / PB;
+    if (((tm128 + kNumXCD - 1) / kNumXCD) * tiles_n > PB_BLOCKS_PER_XCD) return false;
+    const int64_t rem_max = ((tm256 + kNumXCD - 1) / kNumXCD) * tiles_n, rem_all = tm256 * tiles_n;        // (no full round: rem = all tiles)
+    int64_t g = PB_BLOCKS_PER_XCD / rem_max, cap = 64 / rem_all;
+    if (cap < 2) cap = 2;
+    if (g > cap) g = cap;
+    return g <= 2;
+}
+
 // split up to 6 weight operands into planes + inverse row scales with ONE launch
 int launch_split_h2(const H2Operand *ops, int n, float *zero, int zero_n, hipStream_t st, const char *what, float *zero2, int zero2_n) {
     H2SplitBatch b;
@@ -239,6 +266,12 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
     const bool run_mode = a_mode == TOAD_X_F32 && !a_amax && a_amax_out;
     if (run_mode) {
         if (addend || mask_src || mask_bits || pool.T > 0 || a_stride != 1 || !slab_ke) { set_error("%s: the self-measuring operand mode is a plain forward with per-block scales", what); return TOAD_EINVAL; }
+        if (nt_half_tiles(M, N)) {
+            hipLaunchKernelGGL((gemm_nt_h2_big_kernel<false, false, 0, 3, 128>), dim3(PB_GRID), dim3(512), H2_SMEM_RUN, st, A, lda, (const float *)nullptr, planes,
+                               binv, C, ldc, (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                               (const float *)nullptr, (const float *)nullptr, 0, slabs, y_amax, bits_out, (int)((M + 127) / 128), tiles_n, a_stride, y_stride, a_amax_out, slab_ke);
+            return check_launch(what);
+        }
         hipLaunchKernelGGL((gemm_nt_h2_big_kernel<false, false, 0, 3>), dim3(PB_GRID), dim3(512), H2_SMEM_RUN, st, A, lda, (const float *)nullptr, planes,
                            binv, C, ldc, (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
                            (const float *)nullptr, (const float *)nullptr, 0, slabs, y_amax, bits_out, tiles_m, tiles_n, a_stride, y_stride, a_amax_out, slab_ke);
@@ -293,6 +326,22 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
                        (int)N, (int)K, bias, es, addend, msrc, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, bits_out, tiles_m, tiles_n, a_stride, y_stride, (float *)nullptr, (int *)nullptr)
     const int msk = mask_bits ? 2 : (mask_src ? 1 : 0);
     if (mask_bits && !mask_src) { set_error("%s: the one-bit ReLU image needs the fp32 relu_src as well (remainder tiles)", what); return TOAD_EINVAL; }
+    // short operands: half-height tiles, whole K per workgroup, no fix-up launch (the epilogues the MIL step uses; per-block abs-max arrays)
+    if (!addend && msk != 1 && (pool.T == 0 || msk == 2) && a_stride == 1 && y_stride == 1 && nt_half_tiles(M, N)) {
+        const int tm128 = (int)((M + 127) / 128);
+#define TOAD_LAUNCH_H2_HALF(P, M_, AM)                                                                                                   \
+        hipLaunchKernelGGL((gemm_nt_h2_big_kernel<P, false, M_, AM, 128>), dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, a_amax, planes, binv, C, ldc, \
+                           (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, msrc, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, bits_out,    \
+                           tm128, tiles_n, a_stride, y_stride, (float *)nullptr, (int *)nullptr)
+        if (pool.T >> 8) {
+            if ((pool.T & 255) != 2 || !aligned16(pool.a_raw)) { set_error("%s: the batched pooled addend is instantiated for 2 tasks on the one-bit ReLU image", what); return TOAD_EINVAL; }
+            TOAD_LAUNCH_H2_HALF(true, 2, 4);
+        } else if (pool.T > 0) TOAD_LAUNCH_H2_HALF(true, 2, 0);
+        else if (msk == 2) TOAD_LAUNCH_H2_HALF(false, 2, 0);
+        else TOAD_LAUNCH_H2_HALF(false, 0, 0);
+#undef TOAD_LAUNCH_H2_HALF
+        return check_launch(what);
+    }
     if (pool.T >> 8) {       // batched pooled addend: per-row records + per-slide dM (the ragged multi-slide step; gemm_h2_epilogue.inc PBATCH)
         if ((pool.T & 255) != 2 || msk != 2 || !aligned16(pool.a_raw)) { set_error("%s: the batched pooled addend is instantiated for 2 tasks on the one-bit ReLU image", what); return TOAD_EINVAL; }
         hipLaunchKernelGGL((gemm_nt_h2_big_kernel<true, false, 2, 4>), dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, a_amax, planes, binv, C, ldc, (int)M, (int)N, (int)K, bias,
@@ -704,6 +753,53 @@ int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, co
         hipLaunchKernelGGL(slab_reduce_h2_kernel, dim3(rgrid), dim3(256), 0, st, slab, dW, n, cs, db, n2, nsplit, beta, scales);
     else
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, st, slab, dW, n, cs, db, n2, nsplit, beta);
+    return check_launch(what);
+}
+
+// ---- up to three weight gradients of one backward pass in ONE launch (gemm_tn_h2_batch_kernel, gemm_h2.inc) ----------------------------------
+// Plan: as many row splits as keep every item on its own workgroup (PB_GRID / tiles of all products), each at least four 32-row stages deep for
+// bags that have the rows (one stage for tiny ones), all of the same depth.
+struct TnBatchPlan { int nsplit, rows_per_split, tiles_all; };
+static TnBatchPlan tn_batch_plan(int64_t M, const WgradJob *jobs, int n) {
+    TnBatchPlan p{0, 0, 0};
+    for (int i = 0; i < n; ++i) p.tiles_all += (int)(((jobs[i].N + PB - 1) / PB) * ((jobs[i].K + PB - 1) / PB));
+    if (p.tiles_all <= 0 || p.tiles_all > PB_GRID) return p;
+    int64_t s = PB_GRID / p.tiles_all;
+    const int64_t max_splits = M >= 8192 ? (M + 127) / 128 : (M + 31) / 32;
+    if (s > max_splits) s = max_splits;
+    if (s < 1) s = 1;
+    int64_t rps = (M + s - 1) / s;
+    rps = (rps + BK - 1) / BK * BK;
+    p.rows_per_split = (int)rps;
+    p.nsplit = (int)((M + rps - 1) / rps);
+    return p;
+}
+bool toad::wgrad_batch_ok(int64_t M, const WgradJob *jobs, int n, size_t ws_bytes_each) {
+    if (n < 2 || n > 3 || M < 64 || M > kTnBatchMaxRows) return false;
+    const TnBatchPlan p = tn_batch_plan(M, jobs, n);
+    if (p.nsplit < 1) return false;
+    for (int i = 0; i < n; ++i) {
+        if (!jobs[i].dY || !jobs[i].X || !jobs[i].dy_amax || !jobs[i].x_amax || !jobs[i].dW || !jobs[i].ws || !tn_big_ok(M, jobs[i].N, jobs[i].K)) return false;
+        const size_t need = (size_t)p.nsplit * (size_t)(jobs[i].N * jobs[i].K + jobs[i].N) * sizeof(float) + (size_t)(2 * h2_nblk(M) + 64) * sizeof(float);
+        if (need > ws_bytes_each) return false;
+    }
+    return true;
+}
+int toad::launch_wgrad_batch(const WgradJob *jobs, int n, int64_t M, float beta, hipStream_t st, const char *what, WgradDeferred *defer) {
+    const TnBatchPlan p = tn_batch_plan(M, jobs, n);
+    (void)cfg();
+    const float *A[3], *aam[3], *B[3], *bam[3]; float *slab[3], *cs[3], *sc[3]; int I[3], J[3];
+    for (int i = 0; i < 3; ++i) {
+        const WgradJob &j = jobs[i < n ? i : 0];
+        A[i] = j.dY; aam[i] = j.dy_amax; B[i] = j.X; bam[i] = j.x_amax; I[i] = (int)j.N; J[i] = (int)j.K;
+        slab[i] = reinterpret_cast<float *>(j.ws);
+        cs[i] = j.db ? slab[i] + (size_t)p.nsplit * j.N * j.K : nullptr;
+        sc[i] = slab[i] + (size_t)p.nsplit * (size_t)(j.N * j.K + j.N);
+        if (i < n) defer[i] = WgradDeferred{slab[i], j.dW, j.N * j.K, cs[i], j.db, j.db ? j.N : 0, p.nsplit, beta, sc[i]};
+    }
+    hipLaunchKernelGGL(gemm_tn_h2_batch_kernel, dim3(PB_GRID), dim3(512), TN2_SMEM, st, A[0], aam[0], B[0], bam[0], slab[0], cs[0], sc[0], I[0], J[0],
+                       A[1], aam[1], B[1], bam[1], slab[1], cs[1], sc[1], I[1], J[1], A[2], aam[2], B[2], bam[2], slab[2], cs[2], sc[2], I[2], J[2], n, (int)M,
+                       p.rows_per_split, p.nsplit);
     return check_launch(what);
 }
 

@@ -261,15 +261,31 @@ static int backward_body(const MilShape &s, const Params &p, float *const *grads
         TOAD_TRY(launch_pool_bwd(f.P, f.P + s.D, D2, f.H, p.wc, f.A_raw, f.stats, f.M, dM, dA_ext, w.dP, w.dP + s.D, D2, nullptr,
                                  grads[6], grads[7], beta, w.amax_dP, false, w.poolb_ws, w.poolb_ws_bytes, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st));
         WgradDeferred dw[3];
-        ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what, TOAD_X_F32, &dw[0])); ev(9);
+        // Short bags (at most kTnBatchMaxRows rows of a raw fp32 bag): the three weight gradients wait for the end of the pass and run as ONE launch
+        // (launch_wgrad_batch: dP / dZ2 / dZ1 and the saved activations all still exist then) - a third of the slab traffic and two launches less
+        // than three launches of the per-XCD plan. Longer bags keep the interleaved order, where each product fills the chip on its own.
+        const WgradJob wj[3] = {{w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], D2, kL, w.wgrad_ws},
+                                {w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], kL, kL, w.wgrad_ws2},
+                                {w.dZ1, w.amax_dZ1, X, f.amax_x, grads[0], grads[1], kL, kL0, w.wgrad_ws3}};
+        const bool wbatch = x_mode == TOAD_X_F32 && wgrad_batch_ok(N, wj, 3, w.wgrad_ws_bytes);
+        if (!wbatch) { ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what, TOAD_X_F32, &dw[0])); ev(9); }
         // dZ2 = (dP Wab + dH_pool) * (H > 0): the pooling gradient dH_pool is recomputed in the epilogue from A_raw, stats, dM
         ev(10); TOAD_TRY(nt_rows(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, nullptr, f.H, f.bits_h,
                                  H2Pool{f.A_raw, f.stats, dM, kT}, w.slabs, w.amax_dZ2, nullptr, st, what)); ev(11);
-        ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws2, st, what, TOAD_X_F32, &dw[1])); ev(13);
-        ev(14); TOAD_TRY(nt_rows(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, f.bits_h1, nopool,
+        if (!wbatch) { ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws2, st, what, TOAD_X_F32, &dw[1])); ev(13); }
+        // (an fp16 / prepared bag ran its first Linear on 256-row tiles, whose K-split remainder tiles leave no bits; where this dgrad would run on
+        //  half-height tiles - which read the bit image for EVERY tile - it takes the fp32 activations instead)
+        const unsigned long long *bits1 = (x_mode == TOAD_X_F32 || !nt_half_tiles(N < kChunkRows ? N : kChunkRows, kL)) ? f.bits_h1 : nullptr;
+        ev(14); TOAD_TRY(nt_rows(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, bits1, nopool,
                                  w.slabs, w.amax_dZ1, nullptr, st, what)); ev(15);
-        ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, X, x_mode == TOAD_X_PT ? x_amax_pt : f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws3, st, what, x_mode, &dw[2]));
-        TOAD_TRY(launch_wgrad_reduce(dw, 3, st, what)); ev(17);
+        if (wbatch) {         // (bench events: the one launch + the reduction are booked under the first weight gradient's pair, the other two pairs are empty)
+            ev(8); TOAD_TRY(launch_wgrad_batch(wj, 3, N, beta, st, what, dw));
+            TOAD_TRY(launch_wgrad_reduce(dw, 3, st, what)); ev(9);
+            ev(12); ev(13); ev(16); ev(17);
+        } else {
+            ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, X, x_mode == TOAD_X_PT ? x_amax_pt : f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws3, st, what, x_mode, &dw[2]));
+            TOAD_TRY(launch_wgrad_reduce(dw, 3, st, what)); ev(17);
+        }
         if (dX) TOAD_TRY(nt_rows(w.dZ1, kL, w.amax_dZ1, w.planes[W_1T], w.binv[W_1T], dX, kL0, N, kL0, kL, nullptr, plain, nullptr, nullptr, nullptr, nopool,
                                  w.slabs, nullptr, nullptr, st, what));
         return TOAD_OK;
@@ -644,14 +660,24 @@ extern "C" int toad_mil_multi_step_f32(const float *const *params, float *const 
     // the array in a pass of its own over dP: 307 MB read per 100k rows.)
     // ---- backward GEMMs over all rows
     WgradDeferred dw[3];
-    ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what, TOAD_X_F32, &dw[0])); ev(9);
+    const WgradJob wj[3] = {{w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], D2, kL, w.wgrad_ws},
+                            {w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], kL, kL, w.wgrad_ws2},
+                            {w.dZ1, w.amax_dZ1, Xcat, f.amax_x, grads[0], grads[1], kL, kL0, w.wgrad_ws3}};
+    const bool wbatch = wgrad_batch_ok(N, wj, 3, w.wgrad_ws_bytes);          // a short batch: the three weight gradients as one launch at the end (backward_body)
+    if (!wbatch) { ev(8); TOAD_TRY(launch_wgrad(w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], N, D2, kL, beta, w.wgrad_ws, st, what, TOAD_X_F32, &dw[0])); ev(9); }
     // dZ2 = (dP Wab + dH_pool) * (H > 0): dH_pool[row] = sum_t w_t(row) dM_t[slide(row)] recomputed in the epilogue (batched pooled addend)
     ev(10); TOAD_TRY(launch_nt_h2(w.dP, D2, w.amax_dP, w.planes[W_ABT], w.binv[W_ABT], w.dZ2, kL, N, kL, D2, nullptr, msk, nullptr, f.H, f.bits_h,
                                   H2Pool{rowrec, nullptr, ms.dM, kT | (rec_f << 8)}, w.slabs, w.amax_dZ2, nullptr, st, what)); ev(11);
-    ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws2, st, what, TOAD_X_F32, &dw[1])); ev(13);
+    if (!wbatch) { ev(12); TOAD_TRY(launch_wgrad(w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], N, kL, kL, beta, w.wgrad_ws2, st, what, TOAD_X_F32, &dw[1])); ev(13); }
     ev(14); TOAD_TRY(launch_nt_h2(w.dZ2, kL, w.amax_dZ2, w.planes[W_2T], w.binv[W_2T], w.dZ1, kL, N, kL, kL, nullptr, msk, nullptr, f.H1, f.bits_h1, nopool, w.slabs,
                                   w.amax_dZ1, nullptr, st, what)); ev(15);
-    ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, Xcat, f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws3, st, what, TOAD_X_F32, &dw[2]));
-    TOAD_TRY(launch_wgrad_reduce(dw, 3, st, what)); ev(17);
+    if (wbatch) {
+        ev(8); TOAD_TRY(launch_wgrad_batch(wj, 3, N, beta, st, what, dw));
+        TOAD_TRY(launch_wgrad_reduce(dw, 3, st, what)); ev(9);
+        ev(12); ev(13); ev(16); ev(17);
+    } else {
+        ev(16); TOAD_TRY(launch_wgrad(w.dZ1, w.amax_dZ1, Xcat, f.amax_x, grads[0], grads[1], N, kL, kL0, beta, w.wgrad_ws3, st, what, TOAD_X_F32, &dw[2]));
+        TOAD_TRY(launch_wgrad_reduce(dw, 3, st, what)); ev(17);
+    }
     return TOAD_OK;
 }

@@ -91,7 +91,9 @@ class _ScoresFn(torch.autograd.Function):
                 acc = None
                 for j, (d0, d1) in enumerate(db):
                     blk = ops.gate_scores_block_fwd(p, dp_, d0, wc_[t0:t1, d0:d1].contiguous(), bc[t0:t1].contiguous() if j == 0 else zero_b[:t1 - t0],
-                                                    drop_p, sa + j * F_._GOLDEN & _M64, sb + j * F_._GOLDEN & _M64)     # a mask stream per column block
+                                                    drop_p, sa + 2 * j * F_._GOLDEN & _M64, sb + 2 * j * F_._GOLDEN & _M64)
+                    # (a mask stream per column block AND branch: sb = sa + G, so the blocks step by 2 G like the slides of a batch do in
+                    #  csrc/step.hip - with a step of G block j + 1's tanh masks were block j's sigmoid masks)
                     acc = blk if acc is None else acc.add_(blk)
                 a_raw[:, t0:t1] = acc
         ctx.save_for_backward(xp, p, wab, wc_)
@@ -114,7 +116,7 @@ class _ScoresFn(torch.autograd.Function):
         for j, (d0, d1) in enumerate(db):
             for i, (t0, t1) in enumerate(tb):
                 dpa, dpb, dwc_blk, dbc_blk = ops.gate_scores_block_bwd(p, dp_, d0, wc_[t0:t1, d0:d1].contiguous(), da[:, t0:t1].contiguous(), drop_p,
-                                                                       sa + j * F_._GOLDEN & _M64, sb + j * F_._GOLDEN & _M64)
+                                                                       sa + 2 * j * F_._GOLDEN & _M64, sb + 2 * j * F_._GOLDEN & _M64)
                 if i == 0:                                         # dP is linear in dA: the task blocks of one column block add up
                     dp[:, d0:d1], dp[:, dp_ + d0:dp_ + d1] = dpa, dpb
                 else:
