@@ -107,3 +107,22 @@ def test_partitioners():
     assert sorted(sum(parts, [])) == list(range(len(lens)))
     loads = [sum(lens[i] for i in p) for p in parts]
     assert max(loads) <= 100 and min(loads) >= 80
+
+
+def test_dp_constructor_rejects_batch_sizes_the_ragged_call_cannot_take():
+    """batch_rows above the ragged multi-slide call's row limit (32-bit row offsets of the 1024-wide operand) or a per-slide threshold above
+    batch_rows used to fail with a shape error in the MIDDLE of accumulate(), after earlier calls had already written into the gradient bucket;
+    both are constructor errors now (toad_amd/dp.py)."""
+    from toad_amd import TOAD_fc_mtl_concat
+    from toad_amd.dp import SlideShardedDP
+    model = TOAD_fc_mtl_concat(n_classes=18)
+    mk = lambda **kw: SlideShardedDP(model, lambda ps: torch.optim.SGD(ps, lr=0.1), slide_grad_fn=oracle_slide_grad, **kw)    # noqa: E731
+    with pytest.raises(ValueError, match="batch_rows"):
+        mk(batch_rows=SlideShardedDP.MAX_BATCH_ROWS + 1)
+    with pytest.raises(ValueError, match="batch_rows"):
+        mk(batch_rows=0)
+    with pytest.raises(ValueError, match="batch_max_patches"):
+        mk(batch_rows=100_000, batch_max_patches=100_001)
+    dp = mk(batch_rows=SlideShardedDP.MAX_BATCH_ROWS, batch_max_patches=0)
+    assert dp.batch_rows == SlideShardedDP.MAX_BATCH_ROWS and dp.batch_max_patches == 0
+    assert mk().batch_rows == SlideShardedDP.BATCH_ROWS

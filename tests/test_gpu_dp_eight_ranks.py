@@ -94,6 +94,9 @@ def test_eight_rank_reduced_gradient_equals_the_single_process_gradient(cuda):
     for slot, (o, n) in offs.items():
         a, b = g8[o:o + n], g1[o:o + n]
         scale = max(b.abs().max().item(), 1e-30)
+        if slot == "bc":                                                   # exactly zero by the softmax's shift invariance: round-off of dWc-sized terms
+            o2, n2 = offs["wc"]
+            scale = max(scale, g1[o2:o2 + n2].abs().max().item())
         err = (a - b).abs().max().item()
         tol = 2e-3 if slot in ("w1", "b1", "w2", "b2") else 1e-4
         assert err <= tol * scale, (slot, err, scale)

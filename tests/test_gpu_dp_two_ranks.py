@@ -99,6 +99,9 @@ def test_two_ranks_on_the_real_kernels(cuda, balanced):
     for slot, (o, n) in offs_chk.items():
         a, b = g0[o:o + n].view_as(model._slot_params()[slot]), g_single[o:o + n].view_as(model._slot_params()[slot])
         sc = max(b.abs().max().item(), 1e-30)
+        if slot == "bc":                                 # exactly zero by the softmax's shift invariance: round-off of dWc-sized terms
+            ow, nw = offs_chk["wc"]
+            sc = max(sc, g_single[ow:ow + nw].abs().max().item())
         if slot in ("w1", "b1", "w2", "b2"):
             assert_grad_close_or_few_flips(a, b, 2e-6, sc, what=f"two ranks vs one process: {slot}", floor=1e-9)
         else:

@@ -60,6 +60,7 @@ def test_world_two_plumbing_on_one_gpu_over_gloo(cuda, extra, scaling, slides):
     assert len(pr["step_ms"]) == 2 and len(pr["allreduce_us"]) == 2 and len(pr["patches_per_step"]) == 2
     assert pr["patches_per_step"][0] == pr["patches_per_step"][1]              # both configurations shard evenly over two ranks
     assert max(pr["step_ms"]) <= out["ms_per_step"] * 1.05                      # the line's time is the max over ranks (barrier included)
+    assert 0 < pr["scaling_efficiency_vs_per_rank_min"] <= 1.0001               # fastest rank's own step time / the job's step time
     assert out["value"] > 0 and abs(out["value"] - slides * 1e3 / out["ms_per_step"]) <= 1e-2 * out["value"]
 
 
@@ -68,7 +69,7 @@ def test_world_two_plumbing_on_one_gpu_over_gloo(cuda, extra, scaling, slides):
                          ids=["headline", "config4", "config4_ragged"])
 def test_world_eight_plumbing_on_one_gpu_over_gloo(cuda, extra, scaling, slides):
     """The driver's 8-GPU launch shape on the one device a test box has: `bench.py --gpus 8` spawns eight ranks (toad_amd/launch.py), every rank
-    builds its shard (config 4: 8 of the 64 slides, two per ragged multi-slide call), steps with the gradient all-reduce inside, and rank 0
+    builds its shard (config 4: 8 of the 64 slides = 400,000 rows, ONE ragged multi-slide call at the default batch_rows of 524,288), steps with the gradient all-reduce inside, and rank 0
     prints ONE JSON line with the per-rank attribution. `--single-device --backend gloo` is a plumbing switch (RCCL refuses eight ranks on one
     GPU), never a measurement: the value is asserted to be self-consistent, not fast. `--ragged` deals 64 slides of log-normal length with
     dp.shard_by_length: the patch counts per rank must balance to a few percent and cover all 3.2 M patches exactly once."""
@@ -90,6 +91,7 @@ def test_world_eight_plumbing_on_one_gpu_over_gloo(cuda, extra, scaling, slides)
     else:
         assert len(set(pr["patches_per_step"])) == 1 and pr["patches_per_step"][0] == (100000 if not extra else 8 * 50000)
     assert max(pr["step_ms"]) <= out["ms_per_step"] * 1.05
+    assert 0 < pr["scaling_efficiency_vs_per_rank_min"] <= 1.0001
     assert out["value"] > 0 and abs(out["value"] - slides * 1e3 / out["ms_per_step"]) <= 1e-2 * out["value"]
     for key in ("roofline", "roofline_mfma"):
         assert 0 < out[key]["frac"] < 1, key

@@ -5,7 +5,7 @@ import math
 import pytest
 import torch
 
-from tests.helpers import assert_grad_close
+from tests.helpers import assert_grad_close, assert_grad_close_or_few_flips
 
 pytestmark = pytest.mark.gpu
 
@@ -17,11 +17,17 @@ pytestmark = pytest.mark.gpu
 ROUTE_TOL = 5e-6
 
 
-def assert_routes_agree(a, b, what=""):
+def assert_routes_agree(a, b, what="", trunk=False):
+    """trunk: a gradient a ReLU mask reaches (dW1, db1, dW2, db2). The two routes' activations differ by a few ulp, so a pre-activation at round-off
+    of zero may fall on either side of the ReLU: such a LEGITIMATE flip moves the gradient by one patch's rank-one contribution
+    (helpers.assert_grad_close_or_few_flips); everything else must meet ROUTE_TOL."""
     if not a.is_floating_point():
         assert torch.equal(a, b), what
         return
     sc = max(a.abs().max().item(), 1e-30)
+    if trunk:
+        assert_grad_close_or_few_flips(a, b, ROUTE_TOL, sc, what=what)
+        return
     assert (a - b).abs().max().item() <= ROUTE_TOL * sc, (what, (a - b).abs().max().item(), sc)
 
 
@@ -101,7 +107,7 @@ def test_step_on_a_prepared_bag_equals_the_fp32_bag(cuda, n):
         if k == "bab":                                          # column sums of dP that cancel almost completely: round-off of the cancelling terms
             assert (g0[k] - g1[k]).abs().max().item() <= 5e-5 * g0[k].abs().max().item(), k
             continue
-        assert_routes_agree(g0[k], g1[k], k)
+        assert_routes_agree(g0[k], g1[k], k, trunk=k in ("w1", "b1", "w2", "b2"))
     # run-to-run determinism of the prepared path
     l2, lg2, sl2, g2 = _step(model, pb, cuda)
     assert all(torch.equal(g1[k], g2[k]) for k in ops.STEP_SLOTS) and torch.equal(l1, l2)
@@ -158,6 +164,6 @@ def test_module_forward_backward_on_a_prepared_bag(cuda, n):
         if k.endswith("attention_a.0.bias") or k.endswith("attention_b.0.bias"):     # cancellation-dominated column sums (tests/test_gpu_model.py)
             assert (g0[k] - g1[k]).abs().max().item() <= 5e-5 * g0[k].abs().max().item(), k
             continue
-        assert_routes_agree(g0[k], g1[k], k)
+        assert_routes_agree(g0[k], g1[k], k, trunk=k.startswith("attention_net.0.") or k.startswith("attention_net.2."))
     with torch.no_grad():
         assert_routes_agree(model(x, sex, attention_only=True), model(ops.prepare_bag(x), sex, attention_only=True), "attention_only")

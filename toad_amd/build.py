@@ -20,6 +20,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
          "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 
 
+LAST_BUILD = {"compiled": [], "linked": False, "reused": False}      # what the last build() call did (reported by __graft_entry__.build)
+
+
 def _stale(obj: str, deps) -> bool:
     if not os.path.exists(obj):
         return True
@@ -46,11 +49,15 @@ def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "") 
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
+    linked = False
     if force or procs or _stale(lib, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        linked = True
+    global LAST_BUILD
+    LAST_BUILD = {"compiled": [src for src, _ in procs], "linked": linked, "reused": not procs and not linked}
     return lib
 
 

@@ -50,8 +50,8 @@ __device__ __forceinline__ float groups_sum(float v) {
 }
 
 // streamed-once operands (P, H rows) use non-temporal loads: measured in the training step
-// (bench.py, N=100k) the fused forward drops 105.6 -> 80.7 us and the backward 182 -> 167 us;
-// -DTOAD_POOL_PLAIN_LOADS rebuilds the plain-load arm for A/B runs.
+// (bench.py, N=100k) the fused forward drops 105.6 -> 80.7 us and the backward 182 -> 167 us
+// (the plain-load arm was deleted with the other A/B switches in round 4; docs/HISTORY.md has the measurement).
 __device__ __forceinline__ f32x4 ld4s(const float *p) {
     return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
 }

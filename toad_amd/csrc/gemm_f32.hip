@@ -81,11 +81,12 @@ static void cfg() {
         TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 3>), H2_SMEM_RUN);
         TOAD_ATTR((gemm_nt_h2_big_kernel<true, false, 2, 4>), H2_SMEM);          // batched pooled addend (ragged multi-slide step)
         // half-height tiles (short operands; nt_half_tiles below): the MIL step's five epilogues
-        TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 0, 128>), H2_SMEM);
-        TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 2, 0, 128>), H2_SMEM);
-        TOAD_ATTR((gemm_nt_h2_big_kernel<true, false, 2, 0, 128>), H2_SMEM);
-        TOAD_ATTR((gemm_nt_h2_big_kernel<true, false, 2, 4, 128>), H2_SMEM);
-        TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 3, 128>), H2_SMEM_RUN);
+        TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 0, 128>), H2_SMEM_HALF);
+        TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 2, 0, 128>), H2_SMEM_HALF);
+        TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 1, 0, 128>), H2_SMEM_HALF);
+        TOAD_ATTR((gemm_nt_h2_big_kernel<true, false, 2, 0, 128>), H2_SMEM_HALF);
+        TOAD_ATTR((gemm_nt_h2_big_kernel<true, false, 2, 4, 128>), H2_SMEM_HALF);
+        TOAD_ATTR((gemm_nt_h2_big_kernel<false, false, 0, 3, 128>), H2_SMEM_HALF_RUN);
         TOAD_ATTR(gemm_tn_h2_big_kernel<false>, TN2_SMEM);
         TOAD_ATTR(gemm_tn_h2_big_kernel<true>, TN2_SMEM);
         TOAD_ATTR(gemm_tn_h2_batch_kernel, TN2_SMEM);
@@ -267,7 +268,7 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
     if (run_mode) {
         if (addend || mask_src || mask_bits || pool.T > 0 || a_stride != 1 || !slab_ke) { set_error("%s: the self-measuring operand mode is a plain forward with per-block scales", what); return TOAD_EINVAL; }
         if (nt_half_tiles(M, N)) {
-            hipLaunchKernelGGL((gemm_nt_h2_big_kernel<false, false, 0, 3, 128>), dim3(PB_GRID), dim3(512), H2_SMEM_RUN, st, A, lda, (const float *)nullptr, planes,
+            hipLaunchKernelGGL((gemm_nt_h2_big_kernel<false, false, 0, 3, 128>), dim3(PB_GRID), dim3(512), H2_SMEM_HALF_RUN, st, A, lda, (const float *)nullptr, planes,
                                binv, C, ldc, (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
                                (const float *)nullptr, (const float *)nullptr, 0, slabs, y_amax, bits_out, (int)((M + 127) / 128), tiles_n, a_stride, y_stride, a_amax_out, slab_ke);
             return check_launch(what);
@@ -327,10 +328,10 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
     const int msk = mask_bits ? 2 : (mask_src ? 1 : 0);
     if (mask_bits && !mask_src) { set_error("%s: the one-bit ReLU image needs the fp32 relu_src as well (remainder tiles)", what); return TOAD_EINVAL; }
     // short operands: half-height tiles, whole K per workgroup, no fix-up launch (the epilogues the MIL step uses; per-block abs-max arrays)
-    if (!addend && msk != 1 && (pool.T == 0 || msk == 2) && a_stride == 1 && y_stride == 1 && nt_half_tiles(M, N)) {
+    if (!addend && (pool.T == 0 || msk == 2) && a_stride == 1 && y_stride == 1 && nt_half_tiles(M, N)) {
         const int tm128 = (int)((M + 127) / 128);
 #define TOAD_LAUNCH_H2_HALF(P, M_, AM)                                                                                                   \
-        hipLaunchKernelGGL((gemm_nt_h2_big_kernel<P, false, M_, AM, 128>), dim3(PB_GRID), dim3(512), H2_SMEM, st, A, lda, a_amax, planes, binv, C, ldc, \
+        hipLaunchKernelGGL((gemm_nt_h2_big_kernel<P, false, M_, AM, 128>), dim3(PB_GRID), dim3(512), H2_SMEM_HALF, st, A, lda, a_amax, planes, binv, C, ldc, \
                            (int)M, (int)N, (int)K, bias, es, (const float *)nullptr, msrc, pool.a_raw, pool.stats, pool.dM, pool.T, slabs, y_amax, bits_out,    \
                            tm128, tiles_n, a_stride, y_stride, (float *)nullptr, (int *)nullptr)
         if (pool.T >> 8) {
@@ -338,6 +339,7 @@ int launch_nt_h2(const float *A, int64_t lda, const float *a_amax, const unsigne
             TOAD_LAUNCH_H2_HALF(true, 2, 4);
         } else if (pool.T > 0) TOAD_LAUNCH_H2_HALF(true, 2, 0);
         else if (msk == 2) TOAD_LAUNCH_H2_HALF(false, 2, 0);
+        else if (msk == 1) TOAD_LAUNCH_H2_HALF(false, 1, 0);       // (fp32 mask: the per-op dgrad without a bit image; same tiles, same sums as with one)
         else TOAD_LAUNCH_H2_HALF(false, 0, 0);
 #undef TOAD_LAUNCH_H2_HALF
         return check_launch(what);

@@ -142,6 +142,13 @@ class SlideShardedDP:
         self.slide_grad_fn = slide_grad_fn or hip_slide_grad
         self.batch_max_patches = self.BATCH_MAX_PATCHES if batch_max_patches is None else int(batch_max_patches)
         self.batch_rows = self.BATCH_ROWS if batch_rows is None else int(batch_rows)
+        # validated HERE: toad_mil_multi_step_f32 takes at most MAX_BATCH_ROWS concatenated rows (32-bit row offsets of the 1024-wide fp32 operand,
+        # csrc/gemm_f32.hip h2_nt_ok); a larger batch_rows would fail with a shape error in the middle of accumulate(), after earlier calls of the
+        # same step had already written into the gradient bucket
+        if not (0 < self.batch_rows <= self.MAX_BATCH_ROWS):
+            raise ValueError(f"SlideShardedDP: batch_rows must be in [1, {self.MAX_BATCH_ROWS}] (the ragged multi-slide call's row limit), got {self.batch_rows}")
+        if self.batch_max_patches < 0 or self.batch_max_patches > self.batch_rows:
+            raise ValueError(f"SlideShardedDP: batch_max_patches must be in [0, batch_rows = {self.batch_rows}], got {self.batch_max_patches}")
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -164,6 +171,7 @@ class SlideShardedDP:
     # (profiles/r05r_batched_100k.txt; with the materialised gradient it was 459 against 461).
     BATCH_MAX_PATCHES = 262144
     BATCH_ROWS = 524288
+    MAX_BATCH_ROWS = 1_048_575          # (2^32 - 1) // (1024 * 4): rows of a [N, 1024] fp32 operand the NT kernels address with 32-bit byte offsets
 
     def accumulate(self, slides: Sequence[Slide], global_slides: int, overwrite: bool = True, batched: Optional[bool] = None):
         """grads (+)= sum over ``slides`` of d(loss)/d(params) / global_slides. With ``overwrite`` the

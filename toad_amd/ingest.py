@@ -42,7 +42,9 @@ class BagPrefetcher:
         """``arena_rows`` > 0: consecutive fp32 bags are landed BACK TO BACK in device buffers of that many rows (a new buffer when the next bag
         does not fit; a bag longer than the buffer gets an allocation of its own) and handed out as views. Bags that share a buffer are their own
         concatenation, so ``SlideShardedDP`` / ``ops.mil_multi_step`` batch them into one ragged multi-slide call without copying a row
-        (``ops._adjacent_rows``); set it to the DP wrapper's ``batch_rows``. A buffer is released when the last view of it dies.
+        (``ops._adjacent_rows``); set it to the DP wrapper's ``batch_rows``. A buffer is released when the last view of it dies - so ONE retained
+        bag keeps its whole landing buffer alive (``arena_rows`` x features x 4 bytes: 2 GB at 524,288 rows of 1,024 features); hold copies, not
+        views, of bags that must outlive their step. One buffer serves one feature width: a bag of another width starts a fresh buffer.
         ``prepare``: hand the consumer ``ops.PreparedBag`` objects instead of fp32 tensors (toad_bag_prepare_f32, ABI 9): right behind
         its host-to-device copy, on the COPY stream, every bag is brought into the plane-tiled two-piece form the first Linear and its
         weight gradient take by LDS-DMA, and the fp32 copy is released. The training stream then never measures or splits the bag

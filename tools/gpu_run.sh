@@ -21,6 +21,9 @@ for what in "$@"; do
       elif [[ "$arg" == tests/* ]]; then timeout 900 python -m pytest $arg -x -q -m gpu > $OUT/pytest.log 2>&1
       else timeout 900 python -m pytest tests -x -q -m gpu -k "$arg" > $OUT/pytest.log 2>&1; fi
       echo "rc=$?" >> $OUT/pytest.log; tail -15 $OUT/pytest.log ;;
+    testsall)     # the whole GPU suite without -x: every failure of one lease in one log
+      timeout ${arg:-1800} python -m pytest tests -q -m gpu > $OUT/pytest_all.log 2>&1
+      echo "rc=$?" >> $OUT/pytest_all.log; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_all.log | tail -30 ;;
     bench)
       timeout 600 python bench.py ${arg:---steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 3} > $OUT/bench.json 2> $OUT/bench.err
       tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;

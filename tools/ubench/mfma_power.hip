@@ -106,6 +106,7 @@ static void run(const char *name, const h16x8 *opnd, const f32x4 *big, size_t bi
 int main(int argc, char **argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 2.0;
     const int pat = argc > 2 ? atoi(argv[2]) : 0;
+    const int only = argc > 3 ? atoi(argv[3]) : -1;              // run ONE arm (for a power sampler beside it: tools/power_arms.sh); -1 = all four
     h16x8 *opnd; float *out; unsigned long long *clk; f32x4 *big;
     const size_t big_bytes = (size_t)2 << 30;
     (void)hipMalloc(&opnd, 2048 * sizeof(h16x8)); (void)hipMalloc(&out, 1024); (void)hipMalloc(&clk, 512 * 8); (void)hipMalloc(&big, big_bytes);
@@ -124,9 +125,9 @@ int main(int argc, char **argv) {
         free(hb);
     }
     printf("operands: %s\n", pat == 0 ? "random in [-1, 1)" : "zeros");
-    run<0>("MFMAs only", opnd, big, big_bytes / 16, out, clk, secs);
-    run<1>("+ LDS fragment reads", opnd, big, big_bytes / 16, out, clk, secs);
-    run<2>("+ global loads (HBM)", opnd, big, big_bytes / 16, out, clk, secs);
-    run<3>("+ VALU two-piece arithmetic", opnd, big, big_bytes / 16, out, clk, secs);
+    if (only < 0 || only == 0) run<0>("MFMAs only", opnd, big, big_bytes / 16, out, clk, secs);
+    if (only < 0 || only == 1) run<1>("+ LDS fragment reads", opnd, big, big_bytes / 16, out, clk, secs);
+    if (only < 0 || only == 2) run<2>("+ global loads (HBM)", opnd, big, big_bytes / 16, out, clk, secs);
+    if (only < 0 || only == 3) run<3>("+ VALU two-piece arithmetic", opnd, big, big_bytes / 16, out, clk, secs);
     return 0;
 }
