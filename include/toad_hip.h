@@ -28,13 +28,20 @@
 extern "C" {
 #endif
 
-#define TOAD_ABI_VERSION 12
+#define TOAD_ABI_VERSION 13
 
 enum { TOAD_OK = 0, TOAD_EINVAL = -1, TOAD_ESHAPE = -2, TOAD_EWORKSPACE = -3, TOAD_EALIGN = -4 };
 enum { TOAD_ACT_NONE = 0, TOAD_ACT_RELU = 1 };
 
 int toad_abi_version(void);
 const char *toad_last_error(void);
+/* ABI 13 (diagnostic): launches of the exact-fp32 fallback GEMM kernels (gemm_nt_f32_kernel / gemm_tn_f32_kernel) since the library was loaded.
+ * Those kernels serve raw C-ABI callers whose operands the fp16 two-piece kernels cannot take as they are (a reduction that is not a
+ * multiple of 32, an output width that is not a multiple of 4, no workspace, an operand of 2^32 bytes or more). The Python host layer
+ * (toad_amd/ops.py) zero-pads / chunks such operands instead - exact, the padded products are zero - so that every reference-legal
+ * shape (models/model_toad.py:19: Attn_Net_Gated takes any L, D) runs on ONE arithmetic; tests assert this counter stays put. A
+ * monotonic process-wide counter: the one piece of global state in the library, never read on any dispatch path. */
+int64_t toad_fallback_launches(void);
 
 /* ---- Linear layers (fp32-accurate MFMA GEMMs) ---------------------------------------- */
 

@@ -273,6 +273,53 @@ def test_one_bit_relu_image_gives_the_fp32_mask_result(cuda, m):
     assert (a == 0).float().mean().item() > 0.5                                                   # the mask really masks
 
 
+# ---- ONE arithmetic: shapes outside the two-piece kernels' envelope are padded, not rerouted (round 6) ---------------------------------
+
+@pytest.mark.parametrize("m,k,n", [(999, 1000, 512), (300, 36, 200), (64, 100, 30), (1, 8, 4), (63, 520, 766), (2049, 1024, 512)])
+def test_every_linear_shape_runs_on_the_two_piece_kernels(cuda, m, k, n):
+    """toad_linear_h2_ok is false for reductions that are not a multiple of 32 and output widths that are not a multiple of 4 (the reference's
+    nn.Linear / Attn_Net_Gated take any sizes, models/model_toad.py:19): the per-op wrappers zero-pad such operands (exact: padded products are
+    zero) instead of handing them to the library's exact-fp32 fallback kernels. Forward, dgrad and wgrad against fp64, and the library's count
+    of fallback launches (toad_fallback_launches) must not move - also for weight gradients over fewer than 64 rows, which took the fp32 TN
+    kernel until round 6."""
+    from toad_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(m * 31 + k + n)
+    x = torch.randn(m, k, generator=g); w = torch.randn(n, k, generator=g) * 0.1; b = torch.randn(n, generator=g)
+    dy = torch.randn(m, n, generator=g)
+    before = lib.toad_fallback_launches()
+    y = ops.linear_act_fwd(x.to(cuda), w.to(cuda), b.to(cuda), 1)
+    dx = ops.linear_dgrad(dy.to(cuda), ops.transpose(w.to(cuda)))
+    dw, db = ops.linear_wgrad(dy.to(cuda), x.to(cuda))
+    torch.cuda.synchronize()
+    assert lib.toad_fallback_launches() == before, "a public entry point fell back to the exact-fp32 kernels"
+    x64, w64, dy64 = x.double(), w.double(), dy.double()
+    assert _rel(y.cpu(), torch.relu(x64 @ w64.t() + b.double()).float()) <= 1e-5
+    assert _rel(dx.cpu(), (dy64 @ w64).float()) <= 1e-5
+    assert _rel(dw.cpu(), (dy64.t() @ x64).float()) <= 2e-5 and _rel(db.cpu(), dy64.sum(0).float()) <= 2e-5
+    assert y.shape == (m, n) and dx.shape == (m, k) and dw.shape == (n, k)
+
+
+def test_tiny_bags_and_odd_attention_shapes_never_reach_the_fallback_kernels(cuda):
+    """The whole drop-in path on bags of 1, 2 and 63 patches (their weight gradients reduce over fewer than 64 rows) and a standalone
+    Attn_Net_Gated whose L / D are no multiples of 32 / 4: zero launches of the exact-fp32 fallback kernels."""
+    from toad_amd import Attn_Net_Gated, TOAD_fc_mtl_concat, _lib
+    lib = _lib.load()
+    torch.manual_seed(2)
+    model = TOAD_fc_mtl_concat(n_classes=18); model.relocate(); model.train()
+    sex, label, site = torch.ones(1, device=cuda), torch.tensor([3], device=cuda), torch.tensor([1], device=cuda)
+    ce = torch.nn.CrossEntropyLoss()
+    before = lib.toad_fallback_launches()
+    for n in (1, 2, 63):
+        out = model(torch.randn(n, 1024, device=cuda), sex)
+        (ce(out["logits"], label) * 0.75 + ce(out["site_logits"], site) * 0.25).backward()
+    net = Attn_Net_Gated(L=100, D=30, n_tasks=3).to(cuda)
+    a, _ = net(torch.randn(50, 100, device=cuda).requires_grad_(True))
+    a.sum().backward()
+    torch.cuda.synchronize()
+    assert lib.toad_fallback_launches() == before
+
+
 # ---- fp16 feature bags (toad_mil_*_x16_f32) ------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("n", [1, 255, 777, 2049, 20000])

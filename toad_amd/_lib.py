@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtoad_hip.so")      # the one library the product loads (A/B builds: tools/ab/select_lib.py rebinds this in the TOOL's process)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 P, I64, I, F, SZ, U64 = c_void_p, c_int64, c_int, c_float, c_size_t, c_uint64
 
@@ -19,6 +19,7 @@ P, I64, I, F, SZ, U64 = c_void_p, c_int64, c_int, c_float, c_size_t, c_uint64
 SIGNATURES = {
     "toad_abi_version": (I, []),
     "toad_last_error": (c_char_p, []),
+    "toad_fallback_launches": (I64, []),
     "toad_amax_floats": (SZ, [I64]),
     "toad_absmax_rows256_f32": (I, [P, I64, I64, P, P]),
     "toad_linear_h2_ok": (I, [I64, I64, I64]),

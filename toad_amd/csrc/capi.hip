@@ -2,6 +2,7 @@
 #include "common.h"
 
 #include <stdarg.h>
+#include <atomic>
 
 namespace toad {
 
@@ -13,6 +14,9 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+static std::atomic<long long> g_fallback_launches{0};
+void note_fallback_launch() { g_fallback_launches.fetch_add(1, std::memory_order_relaxed); }
 
 int check_launch(const char *what) {
     const hipError_t e = hipGetLastError();
@@ -27,3 +31,4 @@ int check_launch(const char *what) {
 
 extern "C" int toad_abi_version(void) { return TOAD_ABI_VERSION; }
 extern "C" const char *toad_last_error(void) { return toad::g_err; }
+extern "C" int64_t toad_fallback_launches(void) { return (int64_t)toad::g_fallback_launches.load(std::memory_order_relaxed); }

@@ -17,6 +17,7 @@ constexpr int kNumXCD = 8;     // MI355X: 8 XCDs, block b is dispatched to XCD b
 
 void set_error(const char *fmt, ...);
 int check_launch(const char *what);
+void note_fallback_launch();      // an exact-fp32 fallback GEMM kernel was launched (toad_fallback_launches, capi.hip)
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

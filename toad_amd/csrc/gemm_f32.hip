@@ -431,6 +431,7 @@ static int launch_nt(const float *A, int64_t lda, const float *B, int64_t ldb, f
     // the remainder (K % 32 != 0, no workspace, > 2^32-byte operands) for the generic exact-fp32 128x128 kernel.
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     const int grid = kNumXCD * ((tiles_m + kNumXCD - 1) / kNumXCD) * tiles_n;
+    note_fallback_launch();
     hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3(grid), dim3(256), NT_SMEM, st, A, lda, B, ldb, C, ldc, (int)M, (int)N,
                        (int)K, bias, es, addend, mask_src, tiles_m, tiles_n);
     return check_launch(what);
@@ -485,7 +486,7 @@ extern "C" size_t toad_linear_ws_bytes(int64_t M, int64_t N, int64_t K) {
 extern "C" int toad_linear_h2_ok(int64_t M, int64_t N, int64_t K) { return h2_nt_ok(M, N, K, K, N) ? 1 : 0; }
 static bool tn_big_ok(int64_t M, int64_t N, int64_t K);
 // fp16 bags: both the first Linear (NT, A = bag) and its weight gradient (TN, B = bag) must take the fp16 two-piece kernels
-extern "C" int toad_mil_x16_ok(int64_t N) { return (h2_nt_ok(N, 512, 1024, 1024, 512) && tn_big_ok(N, 512, 1024)) ? 1 : 0; }
+extern "C" int toad_mil_x16_ok(int64_t N) { return (N >= 64 && h2_nt_ok(N, 512, 1024, 1024, 512) && tn_big_ok(N, 512, 1024)) ? 1 : 0; }   // (tiny fp16 bags are up-cast)
 extern "C" size_t toad_relu_bits_bytes(int64_t M, int64_t N) {
     if (M <= 0 || N <= 0) return 0;
     return (size_t)((M + PB - 1) / PB) * (size_t)((N + PB - 1) / PB) * 8 * 2 * 64 * sizeof(unsigned long long);   // 8 KB per 256 x 256 tile
@@ -687,7 +688,9 @@ extern "C" int toad_linear_dgrad_f32(const float *dY, const float *WT, const flo
                           H2Pool{pool_a_raw, pool_stats, pool_dM, pool_T}, dx_amax, nullptr, ws, (hipStream_t)stream, what);
 }
 
-static bool tn_big_ok(int64_t M, int64_t N, int64_t K) { return M >= 64 && N >= 4 && K >= 4; }
+// (round 6: any number of rows - until then bags below 64 patches took the exact-fp32 128 x 128 kernel; the staging clamps its row reads and zeroes
+//  rows beyond the operand, so a one-row bag is one 32-row stage like the last stage of any other)
+static bool tn_big_ok(int64_t M, int64_t N, int64_t K) { return M >= 1 && N >= 4 && K >= 4; }
 
 extern "C" size_t toad_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -737,6 +740,7 @@ int toad::launch_wgrad(const float *dY, const float *dy_amax, const float *X, co
         float *cs = db ? slab + (size_t)nsplit * N * K : nullptr;
         const int tiles = p.tiles_i * p.tiles_j;
         const int grid = kNumXCD * ((p.nsplit + kNumXCD - 1) / kNumXCD) * tiles;
+        note_fallback_launch();
         hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(grid), dim3(256), TN_SMEM, st, dY, N, X, K, slab, cs, (int)M, (int)N,
                            (int)K, p.rows_per_split, p.tiles_i, p.tiles_j, p.nsplit);
         rc = check_launch(what);

@@ -156,16 +156,77 @@ def relu_bits_bytes(m: int, n: int) -> int:
     return int(_lib.load().toad_relu_bits_bytes(int(m), int(n)))
 
 
+# ---- ONE arithmetic (round 6) -------------------------------------------------------------------------------------------------------------
+# The fp16 two-piece GEMMs take reductions in whole 32-deep stages, 16-byte output rows and operands they can address with 32-bit row offsets
+# (toad_linear_h2_ok). Every shape TOAD itself builds qualifies; a standalone Attn_Net_Gated of another (L, D) (models/model_toad.py:19 takes any)
+# used to fall through to the exact-fp32 MFMA kernels inside the library (a 5x lower ceiling and another rounding). The per-op wrappers below
+# ZERO-PAD such operands instead - padded products are exactly zero, padded output columns are sliced off - and cut operands of 2^32 bytes and
+# more into row chunks, so every public Python entry point runs on the two-piece kernels (tests/test_gpu_h2.py counts the library's fallback
+# launches: toad_fallback_launches). The exact-fp32 kernels remain in the library only for raw C-ABI callers that pass such shapes unpadded.
+_K_STAGE = 32
+_CHUNK_ROWS = 4092 * 256                        # csrc/step.hip kChunkRows: rows of one NT launch on a 1024-wide fp32 operand (32-bit byte offsets)
+_CHUNK_SEED_STEP = 0xD1B54A32D192ED03          # csrc/step.hip kChunkSeedStep: train-mode dropout stream of row chunk j = seed + j * this
+_M64 = 0xFFFFFFFFFFFFFFFF
+
+
+def _pad_cols(t: Optional[torch.Tensor], to: int) -> Optional[torch.Tensor]:
+    """t [..., c] -> [..., to] with zero columns appended (a copy; only shapes outside the kernels' envelope pay it)."""
+    if t is None or t.shape[-1] == to:
+        return t
+    return torch.nn.functional.pad(t, (0, to - t.shape[-1])).contiguous()
+
+
+def _up(v: int, q: int) -> int:
+    return (v + q - 1) // q * q
+
+
+def _row_chunks(m: int, row_bytes: int):
+    """Row ranges of one NT launch each: whole operand when its bytes fit 32-bit offsets, else multiples of 256 rows."""
+    if m * row_bytes < (1 << 32):
+        return [(0, m)]
+    step = max(256, min(_CHUNK_ROWS, ((1 << 32) - 1) // row_bytes // 256 * 256))
+    return [(r0, min(m, r0 + step)) for r0 in range(0, m, step)]
+
+
 def linear_act_fwd(x, w, b, act: int, out: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0,
                    x_amax: Optional[torch.Tensor] = None, want_amax: bool = False, want_bits: bool = False):
     """Y = dropout_p(act(X W^T + b)); X [M,K], W [N,K], b [N] or None. drop_p = 0 disables dropout.
     x_amax: abs-max array of X (else measured inside). want_amax: also return the abs-max array of Y -> (Y, y_amax).
-    want_bits (act = RELU, h2_ok shapes): also return the one-bit image of Y for the dgrad of this layer -> (Y, y_amax, bits)."""
+    want_bits (act = RELU, h2_ok shapes): also return the one-bit image of Y for the dgrad of this layer -> (Y, y_amax, bits).
+    Shapes outside the two-piece kernels' envelope are zero-padded (K to a multiple of 32, N to a multiple of 4) and operands of >= 2^32 bytes
+    run as row chunks (train-mode dropout then draws chunk j's masks from drop_seed + j * kChunkSeedStep, like the whole-slide calls)."""
     _chk(x, "x"); _chk(w, "w"); _chk(b, "b", allow_none=True); _chk(x_amax, "x_amax", allow_none=True)
     m, k = x.shape
     n, k2 = w.shape
     if k != k2 or (b is not None and b.numel() != n):
         raise ValueError(f"linear_act_fwd: shape mismatch x{tuple(x.shape)} w{tuple(w.shape)}")
+    kp, np_ = _up(k, _K_STAGE), _up(n, 4)
+    chunks = _row_chunks(m, kp * 4)
+    if kp != k or np_ != n or len(chunks) > 1:
+        if drop_p > 0 and np_ != n:
+            raise NotImplementedError("linear_act_fwd: dropout with an output width that is not a multiple of 4")
+        xp, wp = _pad_cols(x, kp), _pad_cols(w, kp)
+        if np_ != n:
+            wp = torch.nn.functional.pad(wp, (0, 0, 0, np_ - n)).contiguous()
+            bp = None if b is None else torch.nn.functional.pad(b, (0, np_ - n)).contiguous()
+        else:
+            bp = b
+        yp = out if (out is not None and np_ == n) else torch.empty((m, np_), dtype=torch.float32, device=x.device)
+        amaxs, bitss = [], []
+        for j, (r0, r1) in enumerate(chunks):
+            xa = None if x_amax is None else x_amax[r0 // 256:(r1 + 255) // 256].contiguous()
+            res = linear_act_fwd(xp[r0:r1], wp, bp, act, out=yp[r0:r1], drop_p=drop_p, drop_seed=(drop_seed + j * _CHUNK_SEED_STEP) & _M64,
+                                 x_amax=xa, want_amax=want_amax or want_bits, want_bits=want_bits and np_ == n)
+            if want_amax or want_bits:
+                amaxs.append(res[1])
+                if want_bits:
+                    bitss.append(res[2] if np_ == n else None)
+        y = yp if np_ == n else yp[:, :n].contiguous()
+        if out is not None and y is not out:
+            out.copy_(y); y = out
+        if want_bits:
+            return y, torch.cat(amaxs), (torch.cat(bitss) if all(t is not None for t in bitss) else None)
+        return (y, torch.cat(amaxs)) if want_amax else y
     y = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=x.device)
     _chk(y, "out")
     lib = _lib.load()
@@ -201,6 +262,33 @@ def linear_dgrad(dy, wt, addend=None, relu_src=None, out: Optional[torch.Tensor]
     k, n2 = wt.shape
     if n != n2:
         raise ValueError("linear_dgrad: shape mismatch")
+    np_, kp = _up(n, _K_STAGE), _up(k, 4)
+    chunks = _row_chunks(m, np_ * 4)
+    if np_ != n or kp != k or len(chunks) > 1:               # outside the two-piece kernels' envelope: zero padding / row chunks (see linear_act_fwd)
+        dyp, wtp = _pad_cols(dy, np_), _pad_cols(wt, np_)
+        if kp != k:
+            wtp = torch.nn.functional.pad(wtp, (0, 0, 0, kp - k)).contiguous()
+            if relu_bits is not None:
+                raise NotImplementedError("linear_dgrad: a bit image with an output width that is not a multiple of 4")
+        addp, srcp = _pad_cols(addend, kp), _pad_cols(relu_src, kp)
+        poolp = None if pool is None else (pool[0], pool[1], _pad_cols(pool[2], kp))
+        dxp = out if (out is not None and kp == k) else torch.empty((m, kp), dtype=torch.float32, device=dy.device)
+        amaxs = []
+        for (r0, r1) in chunks:
+            b0, b1 = r0 // 256, (r1 + 255) // 256
+            bits_c = None
+            if relu_bits is not None:
+                per_blk = relu_bits.numel() // max(amax_floats(m), 1)
+                bits_c = relu_bits[b0 * per_blk:b1 * per_blk]
+            res = linear_dgrad(dyp[r0:r1], wtp, None if addp is None else addp[r0:r1], None if srcp is None else srcp[r0:r1], out=dxp[r0:r1],
+                               mask_scale=mask_scale, pool=None if poolp is None else (poolp[0][r0:r1], poolp[1], poolp[2]),
+                               dy_amax=None if dy_amax is None else dy_amax[b0:b1].contiguous(), want_amax=want_amax, relu_bits=bits_c)
+            if want_amax:
+                amaxs.append(res[1])
+        dxr = dxp if kp == k else dxp[:, :k].contiguous()
+        if out is not None and dxr is not out:
+            out.copy_(dxr); dxr = out
+        return (dxr, torch.cat(amaxs)) if want_amax else dxr
     dx = out if out is not None else torch.empty((m, k), dtype=torch.float32, device=dy.device)
     _chk(dx, "out")
     for t, nm in ((addend, "addend"), (relu_src, "relu_src"), (dx, "out")):
@@ -237,6 +325,20 @@ def linear_wgrad(dy, x, dw: Optional[torch.Tensor] = None, db: Optional[torch.Te
     m2, k = x.shape
     if m != m2:
         raise ValueError("linear_wgrad: shape mismatch")
+    if not prepared and (n % 4 or k % 4):                    # 16-byte rows for the TN kernels: zero columns, sliced off the result
+        np_, kp = _up(n, 4), _up(k, 4)
+        dwp, dbp = linear_wgrad(_pad_cols(dy, np_), _pad_cols(x, kp), None, None, 0.0, want_db or db is not None, dy_amax, x_amax)
+        dwn = dwp[:n, :k]
+        if dw is None:
+            dw = dwn.contiguous()
+        else:
+            dw.mul_(beta).add_(dwn) if beta != 0.0 else dw.copy_(dwn)
+        if dbp is not None:
+            if db is None:
+                db = dbp[:n].contiguous()
+            else:
+                db.mul_(beta).add_(dbp[:n]) if beta != 0.0 else db.copy_(dbp[:n])
+        return dw, db
     if dw is None:
         dw = torch.empty((n, k), dtype=torch.float32, device=dy.device); beta = 0.0
     if db is None and want_db:
