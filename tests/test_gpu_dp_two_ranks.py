@@ -104,8 +104,8 @@ def test_two_ranks_on_the_real_kernels(cuda, balanced):
             sc = max(sc, g_single[ow:ow + nw].abs().max().item())
         if slot in ("w1", "b1", "w2", "b2"):
             assert_grad_close_or_few_flips(a, b, 2e-6, sc, what=f"two ranks vs one process: {slot}", floor=1e-9)
-        else:
-            assert_grad_close(a, b, 2e-6, sc, what=f"two ranks vs one process: {slot}", floor=1e-9)
+        else:                       # (ba, bb, bc: column sums whose terms cancel almost completely - round-off of the TERMS, as in tests/test_gpu_pt.py)
+            assert_grad_close(a, b, 5e-5 if slot in ("ba", "bb", "bc") else 2e-6, sc, what=f"two ranks vs one process: {slot}", floor=1e-9)
     # two Adam steps at lr 1e-3: Adam's update is ~lr * g/|g|, so a round-off-level gradient difference (summation order of the two
     # partial buckets) on a near-zero gradient can move that one parameter by up to lr per step. Hold almost all parameters tight and
     # every parameter inside what two sign flips can do. (The default kernels keep ALL within 2e-5; the TOAD_GEMM_H2=0 arm does not.)
