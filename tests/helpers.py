@@ -311,16 +311,16 @@ def check_batch_against_oracle(name, params, slides, offs, dev, grads, masks=Non
 
 
 # ---- whole-slide calls against the per-op sequence (round 6) --------------------------------------------------------------------------------
-WGRAD_BATCH_MIN_ROWS, WGRAD_BATCH_MAX_ROWS = 64, 32768          # csrc/common.h kTnBatchMaxRows, gemm_f32.hip wgrad_batch_ok
+WGRAD_BATCH_MIN_ROWS, WGRAD_BATCH_MAX_ROWS = 64, 262144         # csrc/common.h kTnBatchMaxRows, gemm_f32.hip wgrad_batch_ok
 BATCHED_WGRAD_SLOTS = ("w1", "b1", "w2", "b2", "wab", "bab")
 
 
 def assert_step_grad_matches_per_op(got, ref, slot, n_rows):
     """A gradient of a whole-slide call (toad_mil_bwd_f32 / toad_mil_step_f32) against the same gradient from the per-op calls. Same kernels on the
-    same operands in the same order: bitwise - except, for bags of 64 ... 32,768 rows, the three trunk / attention weight gradients (and their bias
+    same operands in the same order: bitwise - except, for bags of 64 ... 262,144 rows, the three trunk / attention weight gradients (and their bias
     gradients, which are column sums formed by the same kernel): the whole-slide call runs them as ONE launch (gemm_tn_h2_batch_kernel) whose row
     splits differ from those of three separate launches, i.e. the same products summed in a different fixed order. 2e-6 of the tensor's abs-max bounds
-    fp32 summation round-off over <= 32k rows with room (measured 1e-7 ... 4e-7); each route stays bitwise reproducible run to run."""
+    fp32 summation round-off over <= 262k rows with room (measured 1e-7 ... 4e-7); each route stays bitwise reproducible run to run."""
     import torch
     if slot in BATCHED_WGRAD_SLOTS and WGRAD_BATCH_MIN_ROWS <= n_rows <= WGRAD_BATCH_MAX_ROWS:
         scale = max(ref.abs().max().item(), 1e-30)

@@ -109,8 +109,11 @@ def test_two_ranks_on_the_real_kernels(cuda, balanced):
     # two Adam steps at lr 1e-3: Adam's update is ~lr * g/|g|, so a round-off-level gradient difference (summation order of the two
     # partial buckets) on a near-zero gradient can move that one parameter by up to lr per step. Hold almost all parameters tight and
     # every parameter inside what two sign flips can do. (The default kernels keep ALL within 2e-5; the TOAD_GEMM_H2=0 arm does not.)
+    # (Round 6: the two runs no longer share their tile plans - see above - so EVERY gradient entry differs at round-off level, not only the ones
+    #  summed in two parts; about 1.5 % of the 1.19 M entries are themselves within round-off of zero, and there Adam's g / (|g| + eps) is sign-like.
+    #  The gradient itself is pinned to 2e-6 above; here: every parameter inside the two-step envelope, and at most 5 % outside 2e-5.)
     dpar = (model.flat_parameters().cpu() - p0).abs()
-    assert dpar.max().item() <= 2 * 2 * 1e-3 and (dpar > 2e-5).float().mean().item() <= 1e-3, (dpar.max().item(), (dpar > 2e-5).float().mean().item())
+    assert dpar.max().item() <= 2 * 2 * 1e-3 and (dpar > 2e-5).float().mean().item() <= 5e-2, (dpar.max().item(), (dpar > 2e-5).float().mean().item())
 
     # (iii) reduced gradient == mean of the oracle's per-slide gradients (fp64 yardstick for ReLU-boundary flips)
     offs, _ = model.flat_offsets()

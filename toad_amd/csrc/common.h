@@ -161,7 +161,7 @@ struct WgradDeferred { const float *slab; float *out; int64_t n; const float *sl
 int launch_wgrad_reduce(const WgradDeferred *d, int count, hipStream_t st, const char *what);
 // two or three weight gradients over the SAME M rows in one launch (gemm_tn_h2_batch_kernel): fp32 operands with their abs-max arrays, one slab
 // area (toad_linear_wgrad_ws_bytes) each; always deferred - the caller reduces them with launch_wgrad_reduce
-constexpr int64_t kTnBatchMaxRows = 32768;
+constexpr int64_t kTnBatchMaxRows = 262144;
 struct WgradJob { const float *dY, *dy_amax, *X, *x_amax; float *dW, *db; int64_t N, K; void *ws; };
 bool wgrad_batch_ok(int64_t M, const WgradJob *jobs, int n, size_t ws_bytes_each);
 int launch_wgrad_batch(const WgradJob *jobs, int n, int64_t M, float beta, hipStream_t st, const char *what, WgradDeferred *defer);

@@ -261,9 +261,10 @@ static int backward_body(const MilShape &s, const Params &p, float *const *grads
         TOAD_TRY(launch_pool_bwd(f.P, f.P + s.D, D2, f.H, p.wc, f.A_raw, f.stats, f.M, dM, dA_ext, w.dP, w.dP + s.D, D2, nullptr,
                                  grads[6], grads[7], beta, w.amax_dP, false, w.poolb_ws, w.poolb_ws_bytes, N, kL, s.D, kT, drop_p, ds.sa, ds.sb, st));
         WgradDeferred dw[3];
-        // Short bags (at most kTnBatchMaxRows rows of a raw fp32 bag): the three weight gradients wait for the end of the pass and run as ONE launch
+        // Bags of at most kTnBatchMaxRows rows (raw fp32): the three weight gradients wait for the end of the pass and run as ONE launch
         // (launch_wgrad_batch: dP / dZ2 / dZ1 and the saved activations all still exist then) - a third of the slab traffic and two launches less
-        // than three launches of the per-XCD plan. Longer bags keep the interleaved order, where each product fills the chip on its own.
+        // than three launches of the per-XCD plan: 10k patches 142 -> 86 us, 100k patches 724 -> 661 us of the step's weight-gradient time
+        // (profiles/r06*); at 500k concatenated rows the two orders measure the same, and longer calls keep the interleaved one.
         const WgradJob wj[3] = {{w.dP, w.amax_dP, f.H, f.amax_h, grads[4], grads[5], D2, kL, w.wgrad_ws},
                                 {w.dZ2, w.amax_dZ2, f.H1, f.amax_h1, grads[2], grads[3], kL, kL, w.wgrad_ws2},
                                 {w.dZ1, w.amax_dZ1, X, f.amax_x, grads[0], grads[1], kL, kL0, w.wgrad_ws3}};

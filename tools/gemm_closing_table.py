@@ -10,11 +10,26 @@
 and the reading: the socket sits at its 1,400 W cap for the whole step, so time is ENERGY / power: the energy of the matrix work and the
 energy of moving the bytes ADD (they draw from one budget; overlapping them in time lowers the clock of both), which is why every call lands
 on MFMA-only + traffic and not on their maximum. Usage:
-    python tools/gemm_closing_table.py ab.txt mfma_power.txt hbm_mix.txt step_traffic_dir [N]  > profiles/r05_gemm_closing_table.md"""
+    python tools/gemm_closing_table.py ab.txt mfma_power.txt hbm_mix.txt step_traffic_dir [N] [power_arms.txt]  > profiles/rNN_gemm_closing_table.md
+
+Round 6: the additive form above prices BOTH arms at the full cap, i.e. it counts the board's idle power twice and assumes the
+streaming arm draws the cap, which nobody had measured. With power_arms.txt (tools/power_arms.sh: board power of every arm, sampled while it runs
+alone) the table gains the corrected floor: only DYNAMIC energy adds, and the budget it draws on is cap - idle:
+
+    floor = [ t_mfma * (P_mfma - P_idle) + t_traffic * (P_stream - P_idle) ] / (P_cap - P_idle)"""
 import collections, csv, glob, re, sys
 
 ab, mfma, hbm, tdir = sys.argv[1:5]
 N = int(sys.argv[5]) if len(sys.argv) > 5 else 100000
+power = {}
+if len(sys.argv) > 6:
+    for ln in open(sys.argv[6]):
+        m = re.match(r"(\w+)\s+samples\s+\d+\s+W min\s+[\d.]+ mean\s+([\d.]+)", ln)
+        if m:
+            power[m.group(1)] = float(m.group(2))
+        m = re.search(r"Max Graphics Package Power \(W\):\s*([\d.]+)", ln)
+        if m:
+            power["cap"] = float(m.group(1))
 GEMMS = [("fwd1", 1024, 512, "NT"), ("fwd2", 512, 512, "NT"), ("fwd_ab", 512, 768, "NT"), ("wgrad_ab", 512, 768, "TN"), ("dgrad_ab", 768, 512, "NT"),
          ("wgrad2", 512, 512, "TN"), ("dgrad2", 512, 512, "NT"), ("wgrad1", 1024, 512, "TN")]
 # ---- achieved: mean over the fp32-bag lines of ab_step.py
@@ -61,8 +76,18 @@ print(f"* MFMA-only: `tools/ubench/mfma_power` arm 0 (register operands, random 
       f"1,400 W cap (shader clock {mfma_clk} MHz; nominal 2,500 at 2.4 GHz) = {mfma_tf / 3:.0f} TF fp32-equivalent for three-term products")
 print(f"* traffic: PMC bytes of the same step (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) at the rate `tools/ubench/hbm_mix` reaches for that mix "
       f"(read-only {rate['read']:.2f}, 1R:1W {rate['copy']:.2f}, 2R:1W {rate['2r1w']:.2f} TB/s)\n")
-print("| call | shape (M x K -> N) | GFLOP (2MNK) | achieved us | TF-eq | MFMA-only us | read MB | written MB | traffic us | MFMA-only + traffic | achieved / (sum) | achieved / max |")
-print("|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
+have_p = all(k in power for k in ("idle", "mfma_only", "copy_random", "r2w1_random", "cap"))
+if have_p:
+    dyn_cap = power["cap"] - power["idle"]
+    w_m = (power["mfma_only"] - power["idle"]) / dyn_cap
+    w_t = {"copy": (power["copy_random"] - power["idle"]) / dyn_cap, "2r1w": (power["r2w1_random"] - power["idle"]) / dyn_cap}
+    print(f"* board power of each arm running alone (`tools/power_arms.sh`, rocm-smi, same box, same call): idle **{power['idle']:.0f} W**, MFMA-only loop "
+          f"**{power['mfma_only']:.0f} W**, streaming 1R:1W on random data **{power['copy_random']:.0f} W** (zeros: {power.get('copy_zeros', float('nan')):.0f}), 2R:1W "
+          f"**{power['r2w1_random']:.0f} W** (zeros: {power.get('r2w1_zeros', float('nan')):.0f}), read-only {power.get('read2_random', float('nan')):.0f} W; cap {power['cap']:.0f} W. "
+          f"Dynamic-energy weights: MFMA {w_m:.2f}, 1R:1W {w_t['copy']:.2f}, 2R:1W {w_t['2r1w']:.2f} of the cap's dynamic budget ({dyn_cap:.0f} W)\n")
+print("| call | shape (M x K -> N) | GFLOP (2MNK) | achieved us | TF-eq | MFMA-only us | read MB | written MB | traffic us | MFMA-only + traffic | achieved / (sum) | achieved / max |"
+      + (" dynamic-energy floor us | achieved / floor |" if have_p else ""))
+print("|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|" + ("---:|---:|" if have_p else ""))
 tot = collections.Counter()
 for name, k, n, kind in GEMMS:
     flop = 2.0 * N * k * n
@@ -71,10 +96,15 @@ for name, k, n, kind in GEMMS:
     mix = "2r1w" if kind == "TN" else "copy"                        # TN: two activation streams in, slabs out; NT: one stream in, one out
     t_t = (rd + wrb) * 1e6 / (rate[mix] * 1e12) * 1e6
     a = ach[name]
+    fl = (t_m * w_m + t_t * w_t[mix]) if have_p else 0.0
     print(f"| {name} (`{kern.split('<')[0]}`) | {N:,} x {k} -> {n} | {flop / 1e9:.1f} | {a:.1f} | {flop / a / 1e6:.0f} | {t_m:.1f} | {rd:.0f} | {wrb:.0f} | {t_t:.1f} | "
-          f"{t_m + t_t:.1f} | {a / (t_m + t_t):.2f} | {a / max(t_m, t_t):.2f} |")
-    tot["a"] += a; tot["m"] += t_m; tot["t"] += t_t; tot["f"] += flop
+          f"{t_m + t_t:.1f} | {a / (t_m + t_t):.2f} | {a / max(t_m, t_t):.2f} |" + (f" {fl:.1f} | {a / fl:.2f} |" if have_p else ""))
+    tot["a"] += a; tot["m"] += t_m; tot["t"] += t_t; tot["f"] += flop; tot["fl"] += fl
 print(f"| **chain** | | {tot['f'] / 1e9:.0f} | **{tot['a']:.0f}** | {tot['f'] / tot['a'] / 1e6:.0f} | {tot['m']:.0f} | | | {tot['t']:.0f} | {tot['m'] + tot['t']:.0f} | "
-      f"**{tot['a'] / (tot['m'] + tot['t']):.2f}** | {tot['a'] / max(tot['m'], tot['t']):.2f} |")
+      f"**{tot['a'] / (tot['m'] + tot['t']):.2f}** | {tot['a'] / max(tot['m'], tot['t']):.2f} |" + (f" {tot['fl']:.0f} | **{tot['a'] / tot['fl']:.2f}** |" if have_p else ""))
 print(f"\n`roofline_mfma.frac` against the nominal 833.3 TF: {tot['f'] / tot['a'] / 1e6 / 833.3:.3f}; against the power-capped MFMA-only rate ({mfma_tf / 3:.0f}): "
       f"{tot['f'] / tot['a'] / 1e6 / (mfma_tf / 3):.3f}; against MFMA-only + traffic (energy-additive floor): {(tot['m'] + tot['t']) / tot['a']:.3f}.")
+if have_p:
+    print(f"\nCorrected reading (round 6): with the idle power subtracted and every arm priced at the power it was MEASURED to draw, the chain's floor is "
+          f"{tot['fl']:.0f} us and the chain runs at **{tot['a'] / tot['fl']:.2f}** of it ({(1 - tot['fl'] / tot['a']) * 100:.0f} % above). The round-5 form (both arms at the full cap) "
+          f"gave {tot['m'] + tot['t']:.0f} us / {tot['a'] / (tot['m'] + tot['t']):.2f}: it double-counted {power['idle']:.0f} W of idle power and assumed a streaming kernel draws the cap.")

@@ -41,6 +41,10 @@ for what in "$@"; do
       (cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE \
           --kernel-trace --output-format csv -d $OUT/pmc -o p -- python $ROOT/tools/pmc_step.py ${arg:-100000} 3 > $OUT/pmc.log 2>&1)
       python tools/pmc_table.py $(dirname $(find $OUT/pmc -name "*counter_collection.csv" | head -1)) > $OUT/pmc_step.txt 2>&1; head -30 $OUT/pmc_step.txt ;;
+    pmc2)           # LDS / issue-stall view of the same step: bank conflicts, LDS issue stalls, instruction mix
+      (cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
+          --kernel-trace --output-format csv -d $OUT/pmc2 -o p -- python $ROOT/tools/pmc_step.py ${arg:-100000} 3 > $OUT/pmc2.log 2>&1)
+      python tools/pmc_table.py $(dirname $(find $OUT/pmc2 -name "*counter_collection.csv" | head -1)) > $OUT/pmc2_step.txt 2>&1; head -60 $OUT/pmc2_step.txt ;;
     traffic)        # HBM traffic of the pool kernels: separate FETCH_SIZE / WRITE_SIZE passes (one pass with both aborts on gfx950)
       for c in FETCH_SIZE WRITE_SIZE; do
         (cd /tmp && timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/traffic/$c -o p -- python $ROOT/tools/pmc_pool.py ${arg:-100000} > $OUT/traffic_$c.log 2>&1)
@@ -81,9 +85,11 @@ PY
     mfma)           # what the power cap leaves of the matrix pipe (tools/ubench/mfma_power: arms 0-3, random operands)
       (cd tools/ubench && [ -x mfma_power ] || hipcc --offload-arch=gfx950 -O3 -o mfma_power mfma_power.hip) ; timeout 120 tools/ubench/mfma_power ${arg:-2} > $OUT/mfma_power.txt 2>&1; cat $OUT/mfma_power.txt ;;
     hbm)            # streaming rates of read-only / copy / 2R:1W / 3R:1W kernels (tools/ubench/hbm_mix)
-      (cd tools/ubench && [ -x hbm_mix ] || hipcc --offload-arch=gfx950 -O3 -o hbm_mix hbm_mix.hip) ; timeout 120 tools/ubench/hbm_mix > $OUT/hbm_mix.txt 2>&1; cat $OUT/hbm_mix.txt ;;
+      (cd tools/ubench && [ -x hbm_mix ] || hipcc --offload-arch=gfx950 -O3 -o hbm_mix hbm_mix.hip) ; timeout 120 tools/ubench/hbm_mix 0 -1 1 > $OUT/hbm_mix.txt 2>&1; cat $OUT/hbm_mix.txt ;;     # (random data since round 6: zeros draw ~190 W less)
     closing)        # the GEMM chain's closing table from this call's ab / mfma / hbm / steptraffic outputs
-      python tools/gemm_closing_table.py $OUT/ab.txt $OUT/mfma_power.txt $OUT/hbm_mix.txt $OUT/steptraffic ${arg:-100000} > $OUT/gemm_closing_table.md 2> $OUT/closing.err; cat $OUT/gemm_closing_table.md; tail -3 $OUT/closing.err ;;
+      python tools/gemm_closing_table.py $OUT/ab.txt $OUT/mfma_power.txt $OUT/hbm_mix.txt $OUT/steptraffic ${arg:-100000} $OUT/power_arms.txt > $OUT/gemm_closing_table.md 2> $OUT/closing.err; cat $OUT/gemm_closing_table.md; tail -3 $OUT/closing.err ;;
+    power)          # board power of every arm of the closing tables (tools/power_arms.sh) -> $OUT/power_arms.txt
+      bash tools/power_arms.sh $TAG > $OUT/power_arms.log 2>&1; cat $OUT/power_arms.txt ;;
     xclosing)       # the extractor's closing table from this call's xstats trace + mfma / hbm outputs
       python tools/extractor_closing_table.py $(find $OUT/xprof -name "*kernel_trace.csv" | head -1) $OUT/mfma_power.txt $OUT/hbm_mix.txt ${arg:-512} > $OUT/extractor_closing_table.md 2> $OUT/xclosing.err; cat $OUT/extractor_closing_table.md; tail -3 $OUT/xclosing.err ;;
     smoke)
