@@ -227,7 +227,7 @@ int launch_split_h2(const H2Operand *ops, int n, float *zero, int zero_n, hipStr
         if (i < n) {
             const int tiles_n = (int)((ops[i].N + PB - 1) / PB);
             b.d[i] = H2SplitDesc{ops[i].src, ops[i].sn, ops[i].sk, ops[i].planes, ops[i].binv, (int)ops[i].N, (int)ops[i].K, tiles_n, waves};
-            waves += tiles_n * PB;
+            waves += (ops[i].sn == 1 && ops[i].sk != 1) ? tiles_n * PB / 4 : tiles_n * PB;       // transposed source: a workgroup (4 waves) per 16 rows; else a wave per row
         } else {
             b.d[i] = H2SplitDesc{nullptr, 0, 0, nullptr, nullptr, 0, 0, 0, INT32_MAX};
         }

@@ -42,6 +42,12 @@ for ln in rows:
         ach[name].append(float(re.search(r"\b%s\s+([\d.]+)" % name, ln).group(1)))
     ach["pool_fwd"].append(float(re.search(r"pool_fwd\s+([\d.]+)", ln).group(1)))
 ach = {k: sum(v) / len(v) for k, v in ach.items()}
+# Round 6: calls of at most 262,144 rows run their three weight gradients as ONE launch at the end of the backward (gemm_tn_h2_batch_kernel); the
+# library books that launch (+ the slab reduction) under the first weight gradient's event pair and leaves the other two pairs empty.
+BATCHED = ach["wgrad2"] < 20.0 and ach["wgrad1"] < 20.0
+if BATCHED:
+    ach["wgrad_x3"] = ach["wgrad_ab"] + ach["wgrad2"] + ach["wgrad1"]
+    GEMMS = [g for g in GEMMS if g[3] == "NT"] + [("wgrad_x3", 0, 0, "TN")]
 # ---- MFMA-only rate (arm 0, random operands), TFLOP/s of fp16 MFMA
 m = re.search(r"arm 0[^:]*:\s*[\d.]+ ms,\s*([\d.]+) TFLOP/s.*?shader clock ([\d-]+) MHz", open(mfma).read())
 mfma_tf, mfma_clk = float(m.group(1)), m.group(2)
@@ -62,15 +68,17 @@ def last_step(counter):
     for did, name, v in seq:
         per.setdefault(did, [name, 0.0])[1] += v
     disp = list(per.values())
-    gem = [d for d in disp if d[0].startswith("gemm_nt_h2_big") or d[0].startswith("gemm_tn_h2_big")]
-    return gem[-8:]
+    gem = [d for d in disp if d[0].startswith("gemm_nt_h2_big") or d[0].startswith("gemm_tn_h2_big") or d[0].startswith("gemm_tn_h2_batch")]
+    return gem[-(6 if BATCHED else 8):]
 fe, wr = last_step("FETCH_SIZE"), last_step("WRITE_SIZE")
 order = ["fwd1", "fwd2", "fwd_ab", "wgrad_ab", "dgrad_ab", "wgrad2", "dgrad2", "wgrad1"]     # launch order inside toad_mil_step_f32 (csrc/step.hip)
+if BATCHED:
+    order = ["fwd1", "fwd2", "fwd_ab", "dgrad_ab", "dgrad2", "wgrad_x3"]
 traffic = {}
 for name, (kf, f_kb), (kw, w_kb) in zip(order, fe, wr):
     assert kf == kw, (kf, kw)
     traffic[name] = (2 * f_kb * 1024 / 1e6, w_kb * 1024 / 1e6, kf)
-print(f"# r05: closing table of the GEMM chain, one {N:,}-patch training step on a raw fp32 bag (same box, same gpurun call for every column)\n")
+print(f"# closing table of the GEMM chain, one {N:,}-patch training step on a raw fp32 bag (same box, same gpurun call for every column)\n")
 print(f"* achieved: HIP events around each call inside the running step (`tools/ab_step.py {N} 30`, mean of {len(rows)} runs; step {sum(step_ms) / len(step_ms):.3f} ms)")
 print(f"* MFMA-only: `tools/ubench/mfma_power` arm 0 (register operands, random fp16 data) sustains **{mfma_tf:.0f} TFLOP/s** of `v_mfma_f32_32x32x16_f16` at the "
       f"1,400 W cap (shader clock {mfma_clk} MHz; nominal 2,500 at 2.4 GHz) = {mfma_tf / 3:.0f} TF fp32-equivalent for three-term products")
@@ -90,14 +98,15 @@ print("| call | shape (M x K -> N) | GFLOP (2MNK) | achieved us | TF-eq | MFMA-o
 print("|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|" + ("---:|---:|" if have_p else ""))
 tot = collections.Counter()
 for name, k, n, kind in GEMMS:
-    flop = 2.0 * N * k * n
+    flop = 2.0 * N * k * n if name != "wgrad_x3" else 2.0 * N * (512 * 768 + 512 * 512 + 1024 * 512)
     t_m = 3 * flop / (mfma_tf * 1e12) * 1e6
     rd, wrb, kern = traffic[name]
     mix = "2r1w" if kind == "TN" else "copy"                        # TN: two activation streams in, slabs out; NT: one stream in, one out
     t_t = (rd + wrb) * 1e6 / (rate[mix] * 1e12) * 1e6
     a = ach[name]
     fl = (t_m * w_m + t_t * w_t[mix]) if have_p else 0.0
-    print(f"| {name} (`{kern.split('<')[0]}`) | {N:,} x {k} -> {n} | {flop / 1e9:.1f} | {a:.1f} | {flop / a / 1e6:.0f} | {t_m:.1f} | {rd:.0f} | {wrb:.0f} | {t_t:.1f} | "
+    shape = f"{N:,} x {k} -> {n}" if name != "wgrad_x3" else f"three products over {N:,} rows, one launch + slab reduction"
+    print(f"| {name} (`{kern.split('<')[0]}`) | {shape} | {flop / 1e9:.1f} | {a:.1f} | {flop / a / 1e6:.0f} | {t_m:.1f} | {rd:.0f} | {wrb:.0f} | {t_t:.1f} | "
           f"{t_m + t_t:.1f} | {a / (t_m + t_t):.2f} | {a / max(t_m, t_t):.2f} |" + (f" {fl:.1f} | {a / fl:.2f} |" if have_p else ""))
     tot["a"] += a; tot["m"] += t_m; tot["t"] += t_t; tot["f"] += flop; tot["fl"] += fl
 print(f"| **chain** | | {tot['f'] / 1e9:.0f} | **{tot['a']:.0f}** | {tot['f'] / tot['a'] / 1e6:.0f} | {tot['m']:.0f} | | | {tot['t']:.0f} | {tot['m'] + tot['t']:.0f} | "
