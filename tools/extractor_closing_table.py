@@ -8,11 +8,29 @@ toad_resnet50_trunc_fwd_f32 call (B tiles of 256 x 256)
     achieved / (sum)       against the energy-additive floor (the socket is at its power cap: matrix energy and byte energy add)
 
 and, from the same numbers, what each candidate fusion would save. usage:
-    python tools/extractor_closing_table.py <kernel_trace.csv> mfma_power.txt hbm_mix.txt [B] > profiles/r05_extractor_closing_table.md"""
+    python tools/extractor_closing_table.py <kernel_trace.csv> mfma_power.txt hbm_mix.txt [B] [power_arms.txt] > profiles/rNN_extractor_closing_table.md
+
+Round 6: with power_arms.txt (tools/power_arms.sh) the table gains the CORRECTED floor - only dynamic energy adds, on the budget
+cap - idle, each arm priced at the board power it was measured to draw alone:
+    floor = [ t_mfma * (P_mfma - P_idle) + t_traffic * (P_2R1W - P_idle) ] / (P_cap - P_idle)"""
 import csv, re, sys
 
 trace, mfma, hbm = sys.argv[1:4]
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 512
+power = {}
+if len(sys.argv) > 5 and __import__('os').path.exists(sys.argv[5]):
+    for ln in open(sys.argv[5]):
+        m_ = re.match(r"(\w+)\s+samples\s+\d+\s+W min\s+[\d.]+ mean\s+([\d.]+)", ln)
+        if m_:
+            power[m_.group(1)] = float(m_.group(2))
+        m_ = re.search(r"Max Graphics Package Power \(W\):\s*([\d.]+)", ln)
+        if m_:
+            power["cap"] = float(m_.group(1))
+have_p = all(k in power for k in ("idle", "mfma_only", "r2w1_random", "cap"))
+w_m = w_t = 1.0
+if have_p:
+    dyn = power["cap"] - power["idle"]
+    w_m, w_t = (power["mfma_only"] - power["idle"]) / dyn, (power["r2w1_random"] - power["idle"]) / dyn
 rows = [r for r in csv.DictReader(open(trace))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
@@ -43,23 +61,32 @@ for li, (pl, blocks, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2))
 agg = {}
 for (name, M, K, N, bi, br, bo), (us, kn) in zip(order, last):
     a = agg.setdefault(name, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += us; a[2] += 2.0 * M * K * N; a[3] += bi + br + bo
-print(f"# r05: closing table of the feature extractor, one toad_resnet50_trunc_fwd_f32 call on {B} tiles of 256 x 256 (same box and gpurun call for every column)\n")
+print(f"# closing table of the feature extractor, one toad_resnet50_trunc_fwd_f32 call on {B} tiles of 256 x 256 (same box and gpurun call for every column)\n")
 print(f"* achieved: rocprofv3 --kernel-trace of `tools/extractor_bench.py {B}`, last call in the trace: {call_us:.0f} us from the stem's start to the last kernel's end "
       f"({B / call_us * 1e6:.0f} patches/s); 43 convolution launches {sum(u for u, _ in last):.0f} us, everything else (gathers, average pool, memsets) {other_us:.0f} us")
 print(f"* MFMA-only: `mfma_power` arm 0 = {mfma_tf:.0f} TFLOP/s of fp16 MFMA at the power cap = {mfma_tf / 3:.0f} TF fp32-equivalent; traffic: algorithmic bytes (fp32 NHWC: input once, "
       f"residual once, output once) at `hbm_mix`'s 2R:1W rate, {mix:.2f} TB/s\n")
-print("| layers | n | us (sum) | GFLOP-eq | TF-eq | MFMA-only us | algorithmic GB | traffic us | MFMA-only + traffic | achieved / (sum) |")
-print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
+if have_p:
+    print(f"* board power of each arm alone (`tools/power_arms.sh`, same box, same call): idle {power['idle']:.0f} W, MFMA-only loop {power['mfma_only']:.0f} W, 2R:1W stream on random "
+          f"data {power['r2w1_random']:.0f} W, cap {power['cap']:.0f} W -> dynamic-energy weights {w_m:.2f} (matrix) and {w_t:.2f} (traffic)\n")
+print("| layers | n | us (sum) | GFLOP-eq | TF-eq | MFMA-only us | algorithmic GB | traffic us | MFMA-only + traffic | achieved / (sum) |" + (" dynamic-energy floor us | achieved / floor |" if have_p else ""))
+print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|" + ("---:|---:|" if have_p else ""))
 T = [0.0, 0.0, 0.0, 0.0]
 for name, (c, us, fl, by) in agg.items():
     tm, tt = 3 * fl / (mfma_tf * 1e12) * 1e6, by / (mix * 1e12) * 1e6
-    print(f"| {name} | {c} | {us:.0f} | {fl / 1e9:.0f} | {fl / us / 1e6:.0f} | {tm:.0f} | {by / 1e9:.2f} | {tt:.0f} | {tm + tt:.0f} | {us / (tm + tt):.2f} |")
+    print(f"| {name} | {c} | {us:.0f} | {fl / 1e9:.0f} | {fl / us / 1e6:.0f} | {tm:.0f} | {by / 1e9:.2f} | {tt:.0f} | {tm + tt:.0f} | {us / (tm + tt):.2f} |"
+          + (f" {tm * w_m + tt * w_t:.0f} | {us / (tm * w_m + tt * w_t):.2f} |" if have_p else ""))
     T[0] += us; T[1] += fl; T[2] += tm; T[3] += by
 tt = T[3] / (mix * 1e12) * 1e6
-print(f"| **all 43 convolutions** | 43 | **{T[0]:.0f}** | {T[1] / 1e9:.0f} | {T[1] / T[0] / 1e6:.0f} | {T[2]:.0f} | {T[3] / 1e9:.1f} | {tt:.0f} | {T[2] + tt:.0f} | **{T[0] / (T[2] + tt):.2f}** |")
+print(f"| **all 43 convolutions** | 43 | **{T[0]:.0f}** | {T[1] / 1e9:.0f} | {T[1] / T[0] / 1e6:.0f} | {T[2]:.0f} | {T[3] / 1e9:.1f} | {tt:.0f} | {T[2] + tt:.0f} | **{T[0] / (T[2] + tt):.2f}** |"
+      + (f" {T[2] * w_m + tt * w_t:.0f} | **{T[0] / (T[2] * w_m + tt * w_t):.2f}** |" if have_p else ""))
+if have_p:
+    print(f"\nCorrected reading (round 6): with idle power subtracted and each arm priced at its measured draw the convolutions' floor is {(T[2] * w_m + tt * w_t) / 1e3:.1f} ms and they "
+          f"run at **{T[0] / (T[2] * w_m + tt * w_t):.2f}** of it; the round-5 form (both arms at the full cap) gave {(T[2] + tt) / 1e3:.1f} ms / {T[0] / (T[2] + tt):.2f} and is retracted as a "
+          "closing argument: the call is NOT on its floor, the stem and the wide residual GEMMs stand off it.")
 print(f"\nFraction of the nominal 833.3 TF: {T[1] / (call_us * 1e-6) / 1e12 / 833.3:.3f} (whole call). MFMA-only {T[2] / 1e3:.1f} ms + traffic {tt / 1e3:.1f} ms = "
-      f"{(T[2] + tt) / 1e3:.1f} ms against {T[0] / 1e3:.1f} ms achieved by the convolutions: the call sits on the energy-additive floor of its own algorithm "
-      f"(fp32 NHWC activations between all 43 convolutions, three MFMA terms per product).\n")
+      f"{(T[2] + tt) / 1e3:.1f} ms against {T[0] / 1e3:.1f} ms achieved by the convolutions (the additive form of round 5; see the corrected reading above when the "
+      f"arm powers were measured).\n")
 # ---- what the candidate fusions would buy, priced with the same two rates
 print("## Candidate fusions, priced with the same rates (bytes removed - bytes added by halo re-reads; matrix work added by halo recompute)\n")
 print("| fusion | blocks | bytes removed GB | halo bytes added GB | net GB | extra matrix us | net us saved (additive model) | of the call |")

@@ -22,7 +22,7 @@ import collections, csv, glob, re, sys
 ab, mfma, hbm, tdir = sys.argv[1:5]
 N = int(sys.argv[5]) if len(sys.argv) > 5 else 100000
 power = {}
-if len(sys.argv) > 6:
+if len(sys.argv) > 6 and __import__('os').path.exists(sys.argv[6]):
     for ln in open(sys.argv[6]):
         m = re.match(r"(\w+)\s+samples\s+\d+\s+W min\s+[\d.]+ mean\s+([\d.]+)", ln)
         if m:

@@ -91,7 +91,7 @@ PY
     power)          # board power of every arm of the closing tables (tools/power_arms.sh) -> $OUT/power_arms.txt
       bash tools/power_arms.sh $TAG > $OUT/power_arms.log 2>&1; cat $OUT/power_arms.txt ;;
     xclosing)       # the extractor's closing table from this call's xstats trace + mfma / hbm outputs
-      python tools/extractor_closing_table.py $(find $OUT/xprof -name "*kernel_trace.csv" | head -1) $OUT/mfma_power.txt $OUT/hbm_mix.txt ${arg:-512} > $OUT/extractor_closing_table.md 2> $OUT/xclosing.err; cat $OUT/extractor_closing_table.md; tail -3 $OUT/xclosing.err ;;
+      python tools/extractor_closing_table.py $(find $OUT/xprof -name "*kernel_trace.csv" | head -1) $OUT/mfma_power.txt $OUT/hbm_mix.txt ${arg:-512} $OUT/power_arms.txt > $OUT/extractor_closing_table.md 2> $OUT/xclosing.err; cat $OUT/extractor_closing_table.md; tail -3 $OUT/xclosing.err ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
     *) echo "unknown job $what" ;;
