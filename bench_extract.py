@@ -69,7 +69,7 @@ def cpu_extractor_baseline(n_tiles: int = 8, budget_s: float = 25.0):
                       + ", ".join(f"{k}: {v * 1e3:.0f} ms" for k, v in probe.items()) + "}"}
 
 
-TRAFFIC_FILE = "r05_extractor_traffic.json"      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one extractor call (tools/gpu_run.sh xtraffic)
+TRAFFIC_FILE = "r06_extractor_traffic.json"      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one extractor call (tools/gpu_run.sh xtraffic)
 EXTRACTOR_KERNEL_SOURCES = ("toad_amd/csrc/conv.hip", "toad_amd/csrc/gemm_f32.hip", "toad_amd/csrc/gemm_h2.inc", "toad_amd/csrc/gemm_h2_epilogue.inc",
                             "toad_amd/csrc/gemm_narrow.inc", "toad_amd/csrc/gemm_stream.inc", "toad_amd/csrc/stem_halo.inc", "toad_amd/csrc/common.h")
 
