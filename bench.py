@@ -34,17 +34,24 @@ utils/core_utils_mtl_concat.py:201-234, so nothing about a bag may be computed o
                  loss.backward(), torch.optim.Adam(model.parameters()).step(), zero_grad()
                  (utils/core_utils_mtl_concat.py:206-234), which is what a reference user gets without touching the harness;
   cpu_baseline   the CPU oracle (structurally the reference's PyTorch-CPU op sequence, pinned to the reference in
-                 oracle/pin_against_reference.py) + torch Adam, timed on this box's host cores at its best thread count.
+                 oracle/pin_against_reference.py) + torch Adam, timed on this box's host cores at its best thread count;
+  batched        the data-parallel trainer's own mode on the same bags: five slides per optimiser step through ONE ragged multi-slide call;
+  ingest         (round 6) the same step fed from page-locked HOST memory through toad_amd.ingest.BagPrefetcher(depth=2) - what the reference's loader does per
+                 slide (datasets/dataset_mtl_concat.py:369-373 + utils/core_utils_mtl_concat.py:201) - for fp32 and fp16 bags: slides/s, host-to-device GB/s
+                 against the copy alone, copy / compute overlap. Never `value` (the contract's bags are resident).
 
 --config 2   1 GPU, single 100k-patch bag, fused gated-attention pool FORWARD only; value = algorithmic GB/s; the oracle's
              gated_pool_fwd timed on the host cores beside it.
 --config 3   1 GPU, full step (fwd + CE + bwd + Adam) on 10,000-patch bags, 52 per optimiser step = one full ragged multi-slide call (520k rows);
-             roofline (pool forward launches of the batch) + roofline_mfma + cpu_baseline (>= 10 repetitions).
+             roofline (pool forward launches of the batch) + roofline_mfma + cpu_baseline (>= 10 repetitions); `per_slide` (round 6) = ONE optimiser
+             step per slide, the reference's own train_loop semantics (utils/core_utils_mtl_concat.py:200-234), with its own GEMM roofline fraction
+             (`--slides-per-rank 1` makes that the line's `value`).
 --config 4   64 slides x 50,000 patches per step, slide i on rank i mod G (shard_round_robin), one gradient all-reduce and one
              Adam step per 64 slides: STRONG scaling over G = --gpus; runs at G = 1 too; roofline + roofline_mfma + cpu_baseline
              (one 50,000-patch slide on the host cores).
 Every N > 1 line carries per_rank: each rank's own step time (min / max / per rank), its pool-forward time and the all-reduce time it
-measured, so that a scaling run can attribute lost efficiency to load imbalance, the collective or clock spread between devices.
+measured, and scaling_efficiency_vs_per_rank_min = fastest rank's own step time / the job's step time (max over ranks, closing barrier included),
+so that a scaling run can attribute lost efficiency to load imbalance, the collective or clock spread between devices without a re-run.
 """
 from __future__ import annotations
 
