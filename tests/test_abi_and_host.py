@@ -178,3 +178,36 @@ def test_adjacent_bags_are_their_own_concatenation():
     assert ops._adjacent_rows([pool.half()[0:3], pool.half()[3:4]]) is None  # not fp32
     assert ops._adjacent_rows([a, pool[3:4, :4]]) is None                   # another width / non-contiguous
 
+
+
+def test_cached_weight_table_follows_the_module_tree():
+    """TOAD_fc_mtl_concat._weights() caches the slot -> tensor table it hands to the library (walking the module tree cost 75 us per forward,
+    a tenth of the reference loop's host time on a 10k-patch bag) and re-validates it per call by identity. Every way a caller can change what
+    the model's parameters ARE must be picked up on the next call: a replaced head, a replaced layer inside attention_net, parameter storage
+    moved by hand, a load_state_dict (in place: same objects, new values)."""
+    import torch
+    from toad_amd import TOAD_fc_mtl_concat
+    torch.manual_seed(0)
+    m = TOAD_fc_mtl_concat(n_classes=18)
+    w0 = m._weights()
+    w1 = m._weights()
+    assert all(w0[k] is w1[k] for k in ("w1", "wcls", "wc")) and w0["wab"].data_ptr() == w1["wab"].data_ptr()
+    assert m._is_flat() and w0["wab"].shape == (768, 512) and w0["wab"].data_ptr() == w0["wa"].data_ptr()
+    # a replaced head
+    m.classifier = torch.nn.Linear(513, 18)
+    w2 = m._weights()
+    assert w2["wcls"] is m.classifier.weight and m._is_flat() and w2["wcls"].data_ptr() != w0["wcls"].data_ptr()
+    # a replaced layer inside the Sequential
+    m.attention_net[0] = torch.nn.Linear(1024, 512)
+    w3 = m._weights()
+    assert w3["w1"] is m.attention_net[0].weight and m._is_flat()
+    # storage moved by hand (what .to() / a cast does): re-flattened, values kept
+    keep = m.attention_net[0].bias.detach().clone()
+    m.attention_net[0].bias.data = m.attention_net[0].bias.data.clone()
+    w4 = m._weights()
+    assert m._is_flat() and torch.equal(w4["b1"].detach(), keep)
+    # in-place load: same objects, the table stays valid and shows the new values
+    sd = {k: torch.full_like(v, 0.5) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    w5 = m._weights()
+    assert w5["w2"] is w4["w2"] and float(w5["w2"].detach().mean()) == 0.5 and float(w5["wab"].mean()) == 0.5

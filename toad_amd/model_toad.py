@@ -244,10 +244,34 @@ class TOAD_fc_mtl_concat(nn.Module):
         return {k: (offs[k], sp[k].numel()) for k in sp}, total
 
     def _weights(self) -> Dict[str, torch.Tensor]:
+        """slot -> tensor for the library calls (the Parameter objects themselves + the stacked [Wa;Wb] / [ba;bb] views of the flat buffer).
+        Called once per forward: walking the module tree through nn.Module.__getattr__ and re-deriving the flat layout cost 75 us per call, a
+        tenth of the host time of the reference's loop on a 10k-patch bag (tools/dropin_prof.py; the loop is host-bound there). The dict is
+        therefore cached and re-validated per call by identity: every (sub)module is still the registered child of its parent, every Parameter
+        object is still registered under its name, and its storage still sits at its offset in the flat buffer - ~30 dict lookups and 15
+        data_ptr() calls. Anything else (model.to(), load into new tensors, a replaced layer) takes the slow path and re-flattens."""
+        c = self.__dict__.get("_w_cache")
+        if c is not None:
+            w, flat, base, mods, prm = c
+            if self._flat is flat and flat.data_ptr() == base and all(par.get(key) is child for par, key, child in mods) \
+                    and all(reg.get(name) is q and q.data_ptr() == ptr for reg, name, q, ptr in prm):
+                return dict(w)
         if not self._is_flat():
             self.flatten_parameters()
         w: Dict[str, torch.Tensor] = dict(self._slot_params())
         w.update(self._views)
+        # what the fast path re-validates: the module chain down to every Linear, and every parameter's registration + address
+        net = self.attention_net
+        att = net[len(net) - 1]
+        lin = {"w1": net[0], "b1": net[0], "w2": net[self._idx2], "b2": net[self._idx2], "wa": att.attention_a[0], "ba": att.attention_a[0],
+               "wb": att.attention_b[0], "bb": att.attention_b[0], "wc": att.attention_c, "bc": att.attention_c,
+               "wcls": self.classifier, "bcls": self.classifier, "wsite": self.site_classifier, "bsite": self.site_classifier}
+        mods = [(self._modules, "attention_net", net), (self._modules, "classifier", self.classifier), (self._modules, "site_classifier", self.site_classifier),
+                (net._modules, "0", net[0]), (net._modules, str(self._idx2), net[self._idx2]), (net._modules, str(len(net) - 1), att),
+                (att._modules, "attention_a", att.attention_a), (att._modules, "attention_b", att.attention_b), (att._modules, "attention_c", att.attention_c),
+                (att.attention_a._modules, "0", att.attention_a[0]), (att.attention_b._modules, "0", att.attention_b[0])]
+        prm = [(lin[k]._parameters, "weight" if k.startswith("w") else "bias", w[k], w[k].data_ptr()) for k in self._FLAT_ORDER]
+        self.__dict__["_w_cache"] = (dict(w), self._flat, self._flat.data_ptr(), mods, prm)
         return w
 
     # ---- checkpoints ----------------------------------------------------------------------

@@ -763,23 +763,50 @@ class MilArena:
         """``cached``: carve the arena out of the per-(device, stream) workspace cache instead of a fresh allocation - for forwards
         whose activations nobody will read back (no_grad / eval): the caller must CLONE the outputs it keeps, since the next
         cached forward overwrites them (a view of a fresh arena would pin ~7 KB per patch for as long as any output lives)."""
-        import ctypes
-        lib = _lib.load()
         self.n, self.c, self.d = n, c, d
-        nbytes = int(lib.toad_mil_arena_bytes(n, c, d))
+        nbytes, align, offs = _arena_layout(n, c, d)          # (three library queries, cached per shape: this runs once per forward)
         self.buf = _ws(nbytes, device, "eval_arena")[:nbytes] if cached else torch.empty(nbytes, dtype=torch.uint8, device=device)
-        align = int(lib.toad_mil_buffer_align(n))
         self.base = (-self.buf.data_ptr()) % align
-        offs = (ctypes.c_int64 * len(ARENA_SLOTS))()
-        _lib.check(lib.toad_mil_arena_layout(n, c, d, offs), "toad_mil_arena_layout")
-        self.off = {k: self.base + int(o) for k, o in zip(ARENA_SLOTS, offs)}
+        self.off = offs
 
     def view(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
-        nbytes = int(torch.empty((), dtype=dtype).element_size())
+        nbytes = _ELEM_BYTES[dtype]
         for s_ in shape:
             nbytes *= int(s_)
-        o = self.off[name]
+        o = self.base + self.off[name]
         return self.buf[o:o + nbytes].view(dtype).view(*shape)
+
+
+_ELEM_BYTES = {torch.float32: 4, torch.int64: 8, torch.uint8: 1, torch.float16: 2, torch.int32: 4}
+_ARENA_LAYOUTS = {}
+_SCRATCH_BYTES = {}
+
+
+def _arena_layout(n: int, c: int, d: int):
+    """(arena bytes, base alignment, slot -> offset from the aligned base) of toad_mil_arena_layout, cached per (N, C, D)."""
+    key = (n, c, d)
+    lay = _ARENA_LAYOUTS.get(key)
+    if lay is None:
+        import ctypes
+        lib = _lib.load()
+        offs = (ctypes.c_int64 * len(ARENA_SLOTS))()
+        _lib.check(lib.toad_mil_arena_layout(n, c, d, offs), "toad_mil_arena_layout")
+        lay = (int(lib.toad_mil_arena_bytes(n, c, d)), int(lib.toad_mil_buffer_align(n)), {k: int(o) for k, o in zip(ARENA_SLOTS, offs)})
+        if len(_ARENA_LAYOUTS) > 4096:
+            _ARENA_LAYOUTS.clear()
+        _ARENA_LAYOUTS[key] = lay
+    return lay
+
+
+def _scratch_bytes(n: int, c: int, d: int) -> int:
+    key = (n, c, d)
+    b = _SCRATCH_BYTES.get(key)
+    if b is None:
+        b = int(_lib.load().toad_mil_scratch_bytes(n, c, d))
+        if len(_SCRATCH_BYTES) > 4096:
+            _SCRATCH_BYTES.clear()
+        _SCRATCH_BYTES[key] = b
+    return b
 
 
 def mil_fwd(w, bag, sex, drop_p: float = 0.0, seed: int = 0, attention_only: bool = False,
@@ -794,7 +821,7 @@ def mil_fwd(w, bag, sex, drop_p: float = 0.0, seed: int = 0, attention_only: boo
     n, c, d = _step_dims(w, bag)
     lib = _lib.load()
     arena = MilArena(n, c, d, bag.device, cached=cached_arena)
-    scratch = _ws(lib.toad_mil_scratch_bytes(n, c, d), bag.device, "mil")
+    scratch = _ws(_scratch_bytes(n, c, d), bag.device, "mil")
     with _timed("mil_fwd"):
         if half == 2:
             _lib.check(lib.toad_mil_fwd_xp_f32(_ptr_array(ws_t), _p(bag.planes), _p(bag.amax), _p(sex), n, c, d, float(drop_p), int(seed),
@@ -834,7 +861,7 @@ def mil_bwd(w, grads, beta: float, bag, arena: MilArena, dlogits, dsite, da_ext=
     dev = bag.device
     dx = torch.empty_like(bag) if need_dx else None
     dsex = torch.empty((1,), dtype=torch.float32, device=dev) if need_dsex else None
-    scratch = _ws(lib.toad_mil_scratch_bytes(n, c, d), dev, "mil")
+    scratch = _ws(_scratch_bytes(n, c, d), dev, "mil")
     buf = arena.buf
     with _timed("mil_bwd"):
         if half == 2:
