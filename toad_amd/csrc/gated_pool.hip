@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256) void bwd_partial_reduce_kernel(const float *__
 static int pool_grid(int64_t N, bool bwd = false) {
     const int64_t ntiles = (N + ROWS_PER_BLOCK_STEP - 1) / ROWS_PER_BLOCK_STEP;
     (void)bwd;
-    const int64_t cap = 512;
+    const int64_t cap = 512;                 // (round 6: 256 / 384 / 1024 / 2048 workgroups for bags below 32k patches all measured slower, profiles/r06y_pool_grid_sweep.txt)
     return (int)(ntiles < cap ? ntiles : cap);
 }
 

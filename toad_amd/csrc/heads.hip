@@ -155,73 +155,134 @@ __global__ __launch_bounds__(1024) void heads_ce_fused_kernel(
 #undef TOAD_MV
         sex += b; label += b; site += b; loss_out += 3 * b;
     }
-    extern __shared__ float s_all[];                 // [2][L+1] Mcat | [C] logits | [2] site logits | [C] dlogits | [2] dsite | cache_w: [C+2][L+1] weights
+    extern __shared__ __attribute__((aligned(16))) float s_all[];   // [2][L+1] Mcat | [C] logits | [2] site logits | [C] dlogits | [2] dsite | [C+2] biases | pad to 16 B | cache_w: [C+2][L+1] weights
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int LP = L + 1;
-    float *s_m = s_all, *s_lg = s_all + 2 * LP, *s_sl = s_lg + C, *s_dl = s_sl + 2, *s_ds = s_dl + C;
-    // cache_w: the forward's pass over the head weights also parks them in LDS, so the backward's dM = dlogits . Wcls + dsite . Wsite
-    // reads LDS instead of walking C dependent global loads per thread (that loop was ~10 of this kernel's ~21 us, and the kernel runs
-    // once per slide: 64 times in a 64-slide batch of small bags)
-    float *s_w = s_ds + 2;
+    float *s_m = s_all, *s_lg = s_all + 2 * LP, *s_sl = s_lg + C, *s_dl = s_sl + 2, *s_ds = s_dl + C, *s_b = s_ds + 2;
+    // cache_w: the head weights are parked in LDS, so the backward's dM = dlogits . Wcls + dsite . Wsite reads LDS instead of walking C
+    // dependent global loads per thread (that loop was ~10 of this kernel's ~21 us, and the kernel runs once per slide: 64 times in a
+    // 64-slide batch of small bags)
+    float *s_w = s_all + ((2 * LP + 3 * C + 6 + 3) & ~3);      // 16-byte aligned (vector stores of the weight copy)
+    // Round 6: ONE global round trip in front of the first barrier. The kernel is a latency chain (one workgroup, O(10 kFLOP)): the row
+    // dot products used to walk their weight row with a load -> fma dependency per 64-column step (9 round trips per row, two rows for
+    // the first waves: ~12 of 15.5 us at 18 classes), then fetched the bias, then - in the loss phase - the labels. Now every thread issues
+    // all of its loads back to back - the pooled features, the head weights as ONE flat copy into LDS (eight independent loads in flight per
+    // thread and batch), the biases, the labels - and the dot products read LDS in the same k order (same sums, bit for bit).
     const float sx = sex[0];
-    for (int e = tid; e < 2 * LP; e += 1024) {
-        const int t = e / LP, k = e % LP;
-        const float v = k < L ? M[t * L + k] : sx;
-        s_m[e] = v;
-        Mcat[e] = v;
+    const int64_t lab = label[0], sit = site[0];
+    const int nW = C * LP, nAll = (C + 2) * LP;
+    const bool al16 = ((reinterpret_cast<uintptr_t>(M) | reinterpret_cast<uintptr_t>(Wcls)) & 15) == 0;
+    if (cache_w && al16 && L % 4 == 0 && 2 * L <= 4096 && C + 2 <= 1024 && nW <= 16 * 1024 && 2 * LP <= 2048) {
+        // every load of the thread is unconditional (indices clamped to valid elements) and issued before the first use; the two big pieces -
+        // the pooled features and the classifier rows - move as 16-byte vectors (few instructions: see the note on the backward below)
+        const int nW4 = nW >> 2, m4 = (2 * L) >> 2;
+        const f32x4 mv = ld4(M + 4 * min(tid, m4 - 1));
+        f32x4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wv[u] = ld4(Wcls + 4 * min(tid + 1024 * u, nW4 - 1));
+        const float wt = Wcls[min(4 * nW4 + tid, nW - 1)];                 // the (nW mod 4) elements behind the last whole vector
+        float sv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) sv[u] = Wsite[min(tid + 1024 * u, 2 * LP - 1)];
+        const int bi = min(tid, C + 1);
+        const float bval = *(bi < C ? bcls + bi : bsite + (bi - C));
+        if (tid < m4) {
+            const int e = 4 * tid, t = e >= L ? 1 : 0, o = e + t;          // Mcat[t][k] sits at t * (L + 1) + k
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s_m[o + q] = mv[q]; Mcat[o + q] = mv[q]; }
+        }
+        if (tid < 2) { s_m[tid * LP + L] = sx; Mcat[tid * LP + L] = sx; }
+        if (tid < C + 2) s_b[tid] = bval;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 1024 * u;
+            if (i < nW4) st4(s_w + 4 * i, wv[u]);
+        }
+        if (4 * nW4 + tid < nW) s_w[4 * nW4 + tid] = wt;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 1024 * u;
+            if (i < 2 * LP) s_w[nW + i] = sv[u];
+        }
+    } else {
+        for (int e = tid; e < 2 * LP; e += 1024) {
+            const int t = e / LP, k = e % LP;
+            const float v = k < L ? M[t * L + k] : sx;
+            s_m[e] = v;
+            Mcat[e] = v;
+        }
+        for (int i = tid; i < C + 2; i += 1024) s_b[i] = i < C ? bcls[i] : bsite[i - C];
+        if (cache_w) {
+            for (int base = 0; base < nAll; base += 8 * 1024) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = base + u * 1024 + tid;
+                    v[u] = e < nW ? Wcls[e] : (e < nAll ? Wsite[e - nW] : 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = base + u * 1024 + tid;
+                    if (e < nAll) s_w[e] = v[u];
+                }
+            }
+        }
     }
     __syncthreads();
     for (int r = wave; r < C + 2; r += 16) {
-        const float *w = r < C ? Wcls + (int64_t)r * LP : Wsite + (int64_t)(r - C) * LP;
         const float *x = r < C ? s_m : s_m + LP;
         float p = 0.f;
-        for (int k = lane; k < LP; k += 64) {
-            const float wk = w[k];
-            if (cache_w) s_w[r * LP + k] = wk;
-            p = fmaf(wk, x[k], p);
+        if (cache_w) {
+            const float *w = s_w + r * LP;
+            for (int k = lane; k < LP; k += 64) p = fmaf(w[k], x[k], p);
+        } else {
+            const float *w = r < C ? Wcls + (int64_t)r * LP : Wsite + (int64_t)(r - C) * LP;
+            for (int k = lane; k < LP; k += 64) p = fmaf(w[k], x[k], p);
         }
         p = wave_sum(p);
         if (lane == 0) {
-            if (r < C) { const float v = p + bcls[r]; logits[r] = v; s_lg[r] = v; }
-            else { const float v = p + bsite[r - C]; site_logits[r - C] = v; s_sl[r - C] = v; }
+            const float v = p + s_b[r];
+            if (r < C) { logits[r] = v; s_lg[r] = v; }
+            else { site_logits[r - C] = v; s_sl[r - C] = v; }
         }
     }
     __syncthreads();
     if (wave == 0) wave_softmax_argmax(s_lg, C, Y_prob, Y_hat, lane);
     if (wave == 1) wave_softmax_argmax(s_sl, 2, site_prob, site_hat, lane);
     if (wave == 2) {
-        const float lc = wave_ce(s_lg, C, label[0], w_cls, s_dl, lane);
-        const float ls = wave_ce(s_sl, 2, site[0], w_site, s_ds, lane);
+        const float lc = wave_ce(s_lg, C, lab, w_cls, s_dl, lane);
+        const float ls = wave_ce(s_sl, 2, sit, w_site, s_ds, lane);
         if (lane == 0) { loss_out[0] = w_cls * lc + w_site * ls; loss_out[1] = lc; loss_out[2] = ls; }
     }
     __syncthreads();
     if (dlogits) for (int i = tid; i < C; i += 1024) dlogits[i] = s_dl[i];
     if (dsite && tid < 2) dsite[tid] = s_ds[tid];
-    // backward: (C + 2) weight rows of L+1 columns, then the two dM rows
-    const int total = (C + 3) * LP;
-    for (int e = tid; e < total; e += 1024) {
-        const int r = e / LP, k = e % LP;
-        if (r < C + 2 && !dWcls) continue;              // batched: weight gradients are summed over the slides by heads_wgrad_batch_kernel
-        if (r < C) {
-            const int64_t o = (int64_t)r * LP + k;
-            dWcls[o] = (beta != 0.f ? beta * dWcls[o] : 0.f) + s_dl[r] * s_m[k];
-            if (k == 0) dbcls[r] = (beta != 0.f ? beta * dbcls[r] : 0.f) + s_dl[r];
-        } else if (r < C + 2) {
-            const int c = r - C, o = c * LP + k;
-            dWsite[o] = (beta != 0.f ? beta * dWsite[o] : 0.f) + s_ds[c] * s_m[LP + k];
-            if (k == 0) dbsite[c] = (beta != 0.f ? beta * dbsite[c] : 0.f) + s_ds[c];
-        } else if (k < L) {
-            float d0 = 0.f, d1;
-            if (cache_w) {
-                for (int c = 0; c < C; ++c) d0 = fmaf(s_dl[c], s_w[c * LP + k], d0);
-                d1 = fmaf(s_ds[1], s_w[(C + 1) * LP + k], s_ds[0] * s_w[C * LP + k]);
-            } else {
-                for (int c = 0; c < C; ++c) d0 = fmaf(s_dl[c], Wcls[(int64_t)c * LP + k], d0);
-                d1 = fmaf(s_ds[1], Wsite[LP + k], s_ds[0] * Wsite[k]);
+    // backward: (C + 2) weight rows of L+1 columns (one wave per row, lanes along the row: no index arithmetic per element - the whole kernel
+    // runs on ONE CU, 1,024 threads share 64 lanes per clock, so every instruction per thread is 16 cycles of the launch), then the two dM rows
+    if (dWcls) {                                        // (batched: the weight gradients are summed over the slides by heads_wgrad_batch_kernel)
+        for (int r = wave; r < C + 2; r += 16) {
+            const bool cls = r < C;
+            const float g = cls ? s_dl[r] : s_ds[r - C];
+            const float *x = cls ? s_m : s_m + LP;
+            float *dst = cls ? dWcls + (int64_t)r * LP : dWsite + (int64_t)(r - C) * LP;
+            for (int k = lane; k < LP; k += 64) dst[k] = (beta != 0.f ? beta * dst[k] : 0.f) + g * x[k];
+            if (lane == 0) {
+                float *db = cls ? dbcls + r : dbsite + (r - C);
+                *db = (beta != 0.f ? beta * *db : 0.f) + g;
             }
-            dM[k] = d0;
-            dM[L + k] = d1;
         }
+    }
+    for (int e = tid; e < 2 * L; e += 1024) {           // dM[0, k] = dlogits . Wcls[:, k], dM[1, k] = dsite . Wsite[:, k]
+        const int t = e >= L ? 1 : 0, k = e - t * L;
+        float d;
+        if (t == 0) {
+            d = 0.f;
+            if (cache_w) { for (int c = 0; c < C; ++c) d = fmaf(s_dl[c], s_w[c * LP + k], d); }
+            else { for (int c = 0; c < C; ++c) d = fmaf(s_dl[c], Wcls[(int64_t)c * LP + k], d); }
+        } else {
+            d = cache_w ? fmaf(s_ds[1], s_w[(C + 1) * LP + k], s_ds[0] * s_w[C * LP + k]) : fmaf(s_ds[1], Wsite[LP + k], s_ds[0] * Wsite[k]);
+        }
+        dM[e] = d;
     }
 }
 
@@ -330,7 +391,7 @@ extern "C" int toad_heads_ce_fused_f32(const float *M, const float *sex, const f
     if (!M || !sex || !Wcls || !bcls || !Wsite || !bsite || !label || !site || !Mcat || !logits || !Y_prob || !Y_hat || !site_logits ||
         !site_prob || !site_hat || !loss_out || !dWcls || !dbcls || !dWsite || !dbsite || !dM) { set_error("%s: null pointer", what); return TOAD_EINVAL; }
     if (L <= 0 || L > 8192 || C <= 0 || C > 1024 || C > L) { set_error("%s: unsupported L=%d C=%d", what, L, C); return TOAD_ESHAPE; }
-    size_t smem = (size_t)(2 * (L + 1) + 2 * C + 4) * sizeof(float);
+    size_t smem = (size_t)((2 * (L + 1) + 3 * C + 6 + 3) & ~3) * sizeof(float);
     const size_t wbytes = (size_t)(C + 2) * (L + 1) * sizeof(float);
     const int cache_w = smem + wbytes <= 60 * 1024 ? 1 : 0;          // 18 classes x 513: 41 KB (below the 64 KB a launch gets without an attribute)
     if (cache_w) smem += wbytes;
@@ -346,7 +407,7 @@ int toad::launch_heads_batch(const HeadsBatch &hb, const float *sex, const float
     const char *what = "toad_heads_ce_fused_f32 (batched)";
     if (L <= 0 || L > 8192 || C <= 0 || C > 1024 || C > L || B < 1) { set_error("%s: unsupported L=%d C=%d B=%d", what, L, C, B); return TOAD_ESHAPE; }
     if ((size_t)2 * (L + 1) * sizeof(float) > hb.rec || (size_t)C * sizeof(float) > hb.rec) { set_error("%s: per-slide record too small", what); return TOAD_EWORKSPACE; }
-    size_t smem = (size_t)(2 * (L + 1) + 2 * C + 4) * sizeof(float);
+    size_t smem = (size_t)((2 * (L + 1) + 3 * C + 6 + 3) & ~3) * sizeof(float);
     const size_t wbytes = (size_t)(C + 2) * (L + 1) * sizeof(float);
     const int cache_w = smem + wbytes <= 60 * 1024 ? 1 : 0;
     if (cache_w) smem += wbytes;
