@@ -663,7 +663,7 @@ int toad::ext_stem_nchw_pool(const float *X, const float *Wf, const float *bias,
     hipLaunchKernelGGL(split_planes_narrow_h2_kernel<2>, dim3(16), dim3(256), 0, st, Wf, (int64_t)192, planes, binv, 64, 192, 1, 1, 12, 6);
     if (int rc = check_launch(what)) return rc;
     const int tiles = B * (H / 4);
-    hipLaunchKernelGGL(stem_halo_pool_kernel, dim3(std::min(tiles, PB_GRID)), dim3(256), SH_SMEM, st, X, planes, binv, bias, Yp, B, H, y_gmax, tiles);
+    hipLaunchKernelGGL(stem_halo_pool_kernel, dim3(std::min(tiles, 2 * PB_GRID)), dim3(256), SH_SMEM, st, X, planes, binv, bias, Yp, B, H, y_gmax, tiles);      // two workgroups per CU
     return check_launch(what);
 }
 extern "C" int toad_stem_pool_nchw_f32(const float *X, const float *Wf, const float *bias, float *Yp, int B, int H, int W, void *ws, size_t ws_bytes, void *stream) {
