@@ -1,6 +1,6 @@
 """bench.py — benchmarks of the TOAD gated-attention MIL hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3                      # headline (the driver's run)
+    python bench.py --gpus 1 --steps 20 --warmup 5                      # headline (the driver's run)
     python bench.py --gpus N --steps K --warmup W                        # N > 1 started plainly: re-executes itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W           # (what the driver runs for N > 1; same thing)
@@ -9,7 +9,7 @@
 
 Headline (no --config). A "step" = one optimiser step of slide-sharded data parallel training: every rank runs
 forward + weighted CE + backward over its own synthetic 100,000-patch x 1024-d bag - the RAW fp32 [N,1024] tensor, already
-resident in HBM, measured (abs-max pass) and split into the GEMMs' operand pieces INSIDE the step like every other activation -,
+resident in HBM, measured (by the first GEMM while it converts it, DESIGN.md 5 RUN) and split into the GEMMs' operand pieces INSIDE the step like every other activation -,
 ONE all-reduce of the 4.77 MB flat gradient over RCCL when N > 1, then Adam. value = slides/s over the whole job (N slides per
 step / max-over-ranks step time). Weak scaling. (The reference reloads every bag every epoch, datasets/dataset_mtl_concat.py:369-373 +
 utils/core_utils_mtl_concat.py:201-234, so nothing about a bag may be computed outside the timed region.) The JSON line also carries
