@@ -54,6 +54,19 @@ for i in range(cases):
             # tile's maximum: tests/test_gpu_pt.py ROUTE_TOL)
             for kk in ("logits", "A"):
                 ok = ok and (res[kk].detach() - keep[kk]).abs().max().item() <= 5e-6 * max(keep[kk].abs().max().item(), 1e-30)
+            # The oracle backward runs on the activations THIS route saved (round 6): since the half-height tiles, a raw bag of 2.6k ... 16k patches sums its
+            # first Linear whole-K while the prepared bag's 256-row tiles are K-split - H1 / H of the two routes differ by fp32 round-off, and a pre-activation
+            # within round-off of zero then legitimately flips its ReLU mask (one rank-one term per flip in the trunk gradients: 2 of 40 cases of the first
+            # round-6 sweep, both N = 4095, profiles/r07k_fuzz_sweeps.txt). Masks identical -> everything to 2e-5, as for the raw bag.
+            ar = ops.mil_fwd(w, bag, sex.to(dev))
+            L_, D2_ = w["w2"].shape[0], 2 * w["wa"].shape[0]
+            sv_cpu = orc.Saved(x=x, h1=ar.view("h1", (n, w["w1"].shape[0])).cpu(), h=ar.view("h", (n, L_)).cpu(), p=ar.view("p", (n, D2_)).cpu(),
+                               a_raw=ar.view("a_raw", (n, 2)).cpu(), m=ar.view("m", (2, L_)).cpu(), mcat=ar.view("mcat", (2, L_ + 1)).cpu(), sex=sex)
+            dl, ds = orc.loss_grad(ar.view("logits", (1, c)).cpu(), label, ar.view("site_logits", (1, 2)).cpu(), site)
+            o32 = orc.backward(params, sv_cpu, dl, ds)
+            sv64 = orc.Saved(**{k: (v.double() if (v is not None and v.is_floating_point()) else v) for k, v in sv_cpu.__dict__.items()})
+            og = orc.backward({k: v.double() for k, v in params.items()}, sv64, dl.double(), ds.double())
+            ref_noise = {k: (o32[k].double() - og[k]).abs().max().item() for k in og}
         worst = 0.0
         for k, p in model.named_parameters():
             scale = og[k].abs().max().item()
